@@ -1,0 +1,135 @@
+/*
+ * ddcn_hip.h -- C ABI of libddcn_hip.so, the MI355X (gfx950) replacement for the
+ * reference's CUDA extension `detseg.ops.dcn.deform_conv_cuda`.
+ *
+ * Reference paths below are relative to /root/reference:
+ *   PY = detseg/ops/dcn/deform_conv.py
+ *   H  = detseg/ops/dcn/src/deform_conv_cuda.cpp     (pybind11 module, H:758-775)
+ *   K  = detseg/ops/dcn/src/deform_conv_cuda_kernel.cu
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer to a contiguous NCHW fp32 tensor (tensor.data_ptr()),
+ *     `stream` is a hipStream_t passed as void* (torch.cuda.current_stream().cuda_stream);
+ *   - no entry point allocates, frees or synchronises; scratch (`workspace`) is brought by the
+ *     caller (ddcn_workspace_bytes says how much) -- the reference allocated and zero-filled its
+ *     `columns` tensor inside every call (H:214-216, H:292-293);
+ *   - every function returns 0 (DDCN_OK) or a negative DDCN_ERR_* code and never throws;
+ *     ddcn_strerror() names the code, ddcn_last_error() gives the detail for the calling thread;
+ *   - the library keeps no state between calls and is re-entrant.
+ *
+ * Tensor shapes (K2 = kh*kw, P = Ho*Wo):
+ *   x[N,C,H,W]  weight[Co,C/groups,kh,kw]  bias[Co]  offset[N,dg*2*K2,Ho,Wo]  (channel 2k = dh, 2k+1 = dw)
+ *   mask[N,dg*K2,Ho,Wo]  depth[N,1,H,W]  out/grad_out[N,Co,Ho,Wo]
+ *   columns workspace: [N][C*K2][ld] with ld = ddcn_col_ld(geom) >= P (rows padded to 128 B).
+ */
+#ifndef DDCN_HIP_H
+#define DDCN_HIP_H
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DDCN_VERSION 100
+
+typedef struct ddcn_geom {
+    int N, C, H, W;     /* input  */
+    int Co;             /* output channels */
+    int kh, kw;         /* kernel */
+    int sh, sw;         /* stride */
+    int ph, pw;         /* zero padding */
+    int dh, dw;         /* dilation */
+    int groups;         /* weight groups */
+    int dg;             /* deformable groups (1 for the depth-aware op) */
+    int Ho, Wo;         /* output size; must equal ddcn_infer_output() */
+} ddcn_geom;
+
+enum {
+    DDCN_OK = 0,
+    DDCN_ERR_BAD_ARG = -1,     /* null pointer / non-positive size */
+    DDCN_ERR_SHAPE = -2,       /* geometry inconsistent (channels vs groups, output size, ...) */
+    DDCN_ERR_WORKSPACE = -3,   /* workspace smaller than ddcn_workspace_bytes() */
+    DDCN_ERR_LAUNCH = -4,      /* HIP reported a launch error */
+    DDCN_ERR_UNSUPPORTED = -5, /* size beyond a documented limit */
+    DDCN_ERR_NO_DEVICE = -6    /* no gfx950 device / wrong architecture */
+};
+
+int ddcn_version(void);
+const char *ddcn_strerror(int rc);
+const char *ddcn_last_error(void);
+
+/* Ho = (H + 2p - (d(k-1)+1)) / s + 1 -- PY:71-80 (_infer_shape), H:200-203.  Fills g->Ho, g->Wo. */
+int ddcn_infer_output(ddcn_geom *g);
+/* Checks of the never-called shape_check() H:76-171 plus H:193-198.  0 or DDCN_ERR_SHAPE. */
+int ddcn_check_geom(const ddcn_geom *g);
+/* Leading dimension (floats) of one columns row and bytes of the whole [N][C*K2][ld] workspace. */
+size_t ddcn_col_ld(const ddcn_geom *g);
+size_t ddcn_workspace_bytes(const ddcn_geom *g);
+
+/* ---------------------------------------------------------------- stage level (one launch each) */
+
+/* Bilinear gather, all N images in one launch.  mask == NULL: K:189-242 (deformable_im2col_gpu_kernel);
+ * else K:569-632 (modulated_deformable_im2col_gpu_kernel).  Writes col[N][C*K2][ld]. */
+int ddcn_im2col_f32(const float *x, const float *offset, const float *mask, float *col, const ddcn_geom *g,
+                    void *stream);
+
+/* Fused backward scatter: K:278-334 / K:634-692 (col2im, accumulates into gx) together with
+ * K:372-435 / K:694-766 (col2im_coord, OVERWRITES goff and gmask).  gmask and mask are NULL for the
+ * non-modulated op.  gcol is the [N][C*K2][ld] result of the W^T*grad_out GEMM. */
+int ddcn_col2im_coord_f32(const float *gcol, const float *x, const float *offset, const float *mask, float *gx,
+                          float *goff, float *gmask, const ddcn_geom *g, void *stream);
+
+/* Depth-aware integer-tap gather / scatter: K:868-918 and K:952-996. */
+int ddcn_depthaware_im2col_f32(const float *x, const float *depth, float *col, const ddcn_geom *g, void *stream);
+int ddcn_depthaware_col2im_f32(const float *gcol, const float *depth, float *gx, const ddcn_geom *g,
+                               void *stream);
+
+/* The three contractions the reference hands to at::addmm_ (cuBLAS), here fp32 MFMA kernels:
+ *   G1 H:232-237 / H:430-435   out[n][g]  = W[g] * col[n][g] (+ bias)       (bias may be NULL)
+ *   G2 H:305-308 / H:503-506   col[n][g]  = W[g]^T * grad_out[n][g]
+ *   G3 H:341-346 / H:539-544   gw[g]     += sum_n grad_out[n][g] * col[n][g]^T   (accumulates)
+ *   G4 H:347-353 / H:545-551   gb        += sum_{n,p} grad_out                   (accumulates) */
+int ddcn_gemm_out_f32(const float *weight, const float *col, const float *bias, float *out, const ddcn_geom *g,
+                      void *stream);
+int ddcn_gemm_gcol_f32(const float *weight, const float *grad_out, float *gcol, const ddcn_geom *g, void *stream);
+int ddcn_gemm_gweight_f32(const float *grad_out, const float *col, float *gw, const ddcn_geom *g, void *stream);
+int ddcn_bias_grad_f32(const float *grad_out, float *gb, const ddcn_geom *g, void *stream);
+
+/* ---------------------------------------------------------------- whole-op entry points
+ * One per function of the reference's pybind module (H:758-775).  The reference's `ones` and
+ * `columns` tensor arguments are replaced by (workspace, workspace_bytes); `with_bias` by a NULL
+ * bias / gb pointer; the eight kernel/stride/pad/dilation ints, group and deformable_group by geom.
+ * Backward ACCUMULATES into gx, gw, gb (the reference's Python pre-zeroes them, PY:54-57, PY:126-130)
+ * and OVERWRITES goff / gmask. */
+
+/* replaces deform_conv_cuda_forward (H:173-251) */
+int ddcn_deform_conv_forward_f32(const float *x, const float *weight, const float *bias, const float *offset,
+                                 float *out, void *workspace, size_t workspace_bytes, const ddcn_geom *g,
+                                 void *stream);
+/* replaces deform_conv_cuda_backward (H:253-367) */
+int ddcn_deform_conv_backward_f32(const float *x, const float *weight, const float *offset, const float *grad_out,
+                                  float *gx, float *goff, float *gw, float *gb, void *workspace,
+                                  size_t workspace_bytes, const ddcn_geom *g, void *stream);
+/* replaces modulated_deform_conv_cuda_forward (H:370-449) */
+int ddcn_modulated_deform_conv_forward_f32(const float *x, const float *weight, const float *bias,
+                                           const float *offset, const float *mask, float *out, void *workspace,
+                                           size_t workspace_bytes, const ddcn_geom *g, void *stream);
+/* replaces modulated_deform_conv_cuda_backward (H:451-565) */
+int ddcn_modulated_deform_conv_backward_f32(const float *x, const float *weight, const float *offset,
+                                            const float *mask, const float *grad_out, float *gx, float *goff,
+                                            float *gmask, float *gw, float *gb, void *workspace,
+                                            size_t workspace_bytes, const ddcn_geom *g, void *stream);
+/* replaces depthaware_conv_cuda_forward (H:567-647) */
+int ddcn_depthaware_conv_forward_f32(const float *x, const float *depth, const float *weight, const float *bias,
+                                     float *out, void *workspace, size_t workspace_bytes, const ddcn_geom *g,
+                                     void *stream);
+/* replaces depthaware_conv_cuda_backward (H:649-756); no gradient flows to depth (PY:207) */
+int ddcn_depthaware_conv_backward_f32(const float *x, const float *depth, const float *weight,
+                                      const float *grad_out, float *gx, float *gw, float *gb, void *workspace,
+                                      size_t workspace_bytes, const ddcn_geom *g, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DDCN_HIP_H */

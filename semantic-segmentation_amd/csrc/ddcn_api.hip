@@ -1,0 +1,287 @@
+// extern "C" surface of libddcn_hip.so (declared in include/ddcn_hip.h) and the host orchestration
+// that replaces detseg/ops/dcn/src/deform_conv_cuda.cpp (H below):
+//   forward : im2col (all images) -> G1 (+bias)                         H:221-250 / H:419-448
+//   backward: G2 -> fused col2im+coord -> im2col -> G3 (+G4 bias grad)  H:299-363 / H:497-561
+// No allocation, no synchronisation, no per-image host loop; the columns scratch is caller memory.
+#include <stdarg.h>
+#include <stdio.h>
+
+#include "ddcn_common.h"
+
+namespace ddcn {
+
+static thread_local char g_err[512] = "";
+
+int fail(int rc, const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return rc;
+}
+
+int check_launch(const char *what)
+{
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(DDCN_ERR_LAUNCH, "%s: %s", what, hipGetErrorString(e));
+    return DDCN_OK;
+}
+
+static int check_geom(const ddcn_geom *g)
+{
+    if (!g) return fail(DDCN_ERR_BAD_ARG, "geom is NULL");
+    if (g->N <= 0 || g->C <= 0 || g->H <= 0 || g->W <= 0 || g->Co <= 0)
+        return fail(DDCN_ERR_SHAPE, "non-positive tensor size N=%d C=%d H=%d W=%d Co=%d", g->N, g->C, g->H, g->W, g->Co);
+    if (g->kh <= 0 || g->kw <= 0)
+        return fail(DDCN_ERR_SHAPE, "kernel size should be greater than zero, but got kH: %d kW: %d", g->kh, g->kw);
+    if (g->sh <= 0 || g->sw <= 0)
+        return fail(DDCN_ERR_SHAPE, "stride should be greater than zero, but got dH: %d dW: %d", g->sh, g->sw);
+    if (g->dh <= 0 || g->dw <= 0)
+        return fail(DDCN_ERR_SHAPE, "dilation should be greater than 0, but got dilationH: %d dilationW: %d", g->dh, g->dw);
+    if (g->ph < 0 || g->pw < 0) return fail(DDCN_ERR_SHAPE, "negative padding");
+    if (g->groups <= 0 || g->C % g->groups || g->Co % g->groups)
+        return fail(DDCN_ERR_SHAPE, "Input shape and kernel channels wont match: C=%d Co=%d groups=%d", g->C, g->Co, g->groups);
+    if (g->dg <= 0 || g->C % g->dg)
+        return fail(DDCN_ERR_SHAPE, "input channels must divide deformable group size (C=%d dg=%d)", g->C, g->dg);
+    ddcn_geom t = *g;
+    ddcn_infer_output(&t);
+    if (t.Ho < 1 || t.Wo < 1)
+        return fail(DDCN_ERR_SHAPE, "Given input size: (%d x %d x %d). Calculated output size: (%d x %d x %d). Output size is too small",
+                    g->C, g->H, g->W, g->Co, t.Ho, t.Wo);
+    if (t.Ho != g->Ho || t.Wo != g->Wo)
+        return fail(DDCN_ERR_SHAPE, "invalid spatial size of offset/output, expected height: %d width: %d, but got height: %d width: %d",
+                    t.Ho, t.Wo, g->Ho, g->Wo);
+    const Dims d = dims_of(*g);
+    // 32-bit index budget of the kernels (per-image planes and column rows)
+    if ((long)g->H * g->W >= (1L << 31) || (long)d.P >= (1L << 31) - 1024 || (long)d.Ktot >= (1L << 31))
+        return fail(DDCN_ERR_UNSUPPORTED, "tensor plane exceeds 2^31 elements");
+    return DDCN_OK;
+}
+
+static int check_ws(const ddcn_geom *g, const void *ws, size_t bytes)
+{
+    if (!ws) return fail(DDCN_ERR_BAD_ARG, "workspace is NULL");
+    const size_t need = ddcn_workspace_bytes(g);
+    if (bytes < need) return fail(DDCN_ERR_WORKSPACE, "workspace too small: %zu < %zu bytes", bytes, need);
+    if ((uintptr_t)ws & 15) return fail(DDCN_ERR_BAD_ARG, "workspace must be 16-byte aligned");
+    return DDCN_OK;
+}
+
+}  // namespace ddcn
+
+using namespace ddcn;
+
+#define REQUIRE(p)                                                          \
+    do {                                                                    \
+        if (!(p)) return fail(DDCN_ERR_BAD_ARG, "%s: " #p " is NULL", __func__); \
+    } while (0)
+#define TRY(expr)              \
+    do {                       \
+        int rc_ = (expr);      \
+        if (rc_ != DDCN_OK) return rc_; \
+    } while (0)
+
+extern "C" {
+
+int ddcn_version(void) { return DDCN_VERSION; }
+
+const char *ddcn_strerror(int rc)
+{
+    switch (rc) {
+    case DDCN_OK: return "ok";
+    case DDCN_ERR_BAD_ARG: return "bad argument";
+    case DDCN_ERR_SHAPE: return "shape mismatch";
+    case DDCN_ERR_WORKSPACE: return "workspace too small";
+    case DDCN_ERR_LAUNCH: return "HIP launch failure";
+    case DDCN_ERR_UNSUPPORTED: return "unsupported size";
+    case DDCN_ERR_NO_DEVICE: return "no gfx950 device";
+    default: return "unknown error";
+    }
+}
+
+const char *ddcn_last_error(void) { return g_err; }
+
+int ddcn_infer_output(ddcn_geom *g)
+{
+    if (!g) return fail(DDCN_ERR_BAD_ARG, "geom is NULL");
+    if (g->sh <= 0 || g->sw <= 0) return fail(DDCN_ERR_SHAPE, "stride should be greater than zero");
+    // floor division like Python's // (PY:76-79): numerator may be negative for too-small inputs
+    const int nh = g->H + 2 * g->ph - (g->dh * (g->kh - 1) + 1);
+    const int nw = g->W + 2 * g->pw - (g->dw * (g->kw - 1) + 1);
+    g->Ho = (nh >= 0 ? nh / g->sh : -((-nh + g->sh - 1) / g->sh)) + 1;
+    g->Wo = (nw >= 0 ? nw / g->sw : -((-nw + g->sw - 1) / g->sw)) + 1;
+    return DDCN_OK;
+}
+
+int ddcn_check_geom(const ddcn_geom *g) { return check_geom(g); }
+
+size_t ddcn_col_ld(const ddcn_geom *g) { return g ? (size_t)dims_of(*g).ld : 0; }
+
+size_t ddcn_workspace_bytes(const ddcn_geom *g)
+{
+    if (!g) return 0;
+    const Dims d = dims_of(*g);
+    return sizeof(float) * (size_t)g->N * (size_t)d.Ktot * (size_t)d.ld;
+}
+
+/* ------------------------------------------------------------------ stage level */
+
+int ddcn_im2col_f32(const float *x, const float *offset, const float *mask, float *col, const ddcn_geom *g,
+                    void *stream)
+{
+    REQUIRE(x); REQUIRE(offset); REQUIRE(col);
+    TRY(check_geom(g));
+    return launch_im2col(x, offset, mask, col, *g, (hipStream_t)stream);
+}
+
+int ddcn_col2im_coord_f32(const float *gcol, const float *x, const float *offset, const float *mask, float *gx,
+                          float *goff, float *gmask, const ddcn_geom *g, void *stream)
+{
+    REQUIRE(gcol); REQUIRE(x); REQUIRE(offset); REQUIRE(gx); REQUIRE(goff);
+    if ((mask == nullptr) != (gmask == nullptr)) return fail(DDCN_ERR_BAD_ARG, "mask and gmask must both be given or both be NULL");
+    TRY(check_geom(g));
+    return launch_col2im_coord(gcol, x, offset, mask, gx, goff, gmask, *g, (hipStream_t)stream);
+}
+
+int ddcn_depthaware_im2col_f32(const float *x, const float *depth, float *col, const ddcn_geom *g, void *stream)
+{
+    REQUIRE(x); REQUIRE(depth); REQUIRE(col);
+    TRY(check_geom(g));
+    return launch_depthaware_im2col(x, depth, col, *g, (hipStream_t)stream);
+}
+
+int ddcn_depthaware_col2im_f32(const float *gcol, const float *depth, float *gx, const ddcn_geom *g, void *stream)
+{
+    REQUIRE(gcol); REQUIRE(depth); REQUIRE(gx);
+    TRY(check_geom(g));
+    return launch_depthaware_col2im(gcol, depth, gx, *g, (hipStream_t)stream);
+}
+
+int ddcn_gemm_out_f32(const float *weight, const float *col, const float *bias, float *out, const ddcn_geom *g,
+                      void *stream)
+{
+    REQUIRE(weight); REQUIRE(col); REQUIRE(out);
+    TRY(check_geom(g));
+    return launch_gemm_out(weight, col, bias, out, *g, (hipStream_t)stream);
+}
+
+int ddcn_gemm_gcol_f32(const float *weight, const float *grad_out, float *gcol, const ddcn_geom *g, void *stream)
+{
+    REQUIRE(weight); REQUIRE(grad_out); REQUIRE(gcol);
+    TRY(check_geom(g));
+    return launch_gemm_gcol(weight, grad_out, gcol, *g, (hipStream_t)stream);
+}
+
+int ddcn_gemm_gweight_f32(const float *grad_out, const float *col, float *gw, const ddcn_geom *g, void *stream)
+{
+    REQUIRE(grad_out); REQUIRE(col); REQUIRE(gw);
+    TRY(check_geom(g));
+    return launch_gemm_gweight(grad_out, col, gw, *g, (hipStream_t)stream);
+}
+
+int ddcn_bias_grad_f32(const float *grad_out, float *gb, const ddcn_geom *g, void *stream)
+{
+    REQUIRE(grad_out); REQUIRE(gb);
+    TRY(check_geom(g));
+    return launch_bias_grad(grad_out, gb, *g, (hipStream_t)stream);
+}
+
+/* ------------------------------------------------------------------ whole ops */
+
+static int deform_forward(const float *x, const float *weight, const float *bias, const float *offset,
+                          const float *mask, float *out, void *ws, size_t ws_bytes, const ddcn_geom *g, void *stream)
+{
+    TRY(check_geom(g));
+    TRY(check_ws(g, ws, ws_bytes));
+    hipStream_t s = (hipStream_t)stream;
+    float *col = (float *)ws;
+    TRY(launch_im2col(x, offset, mask, col, *g, s));
+    TRY(launch_gemm_out(weight, col, bias, out, *g, s));
+    return DDCN_OK;
+}
+
+static int deform_backward(const float *x, const float *weight, const float *offset, const float *mask,
+                           const float *gout, float *gx, float *goff, float *gmask, float *gw, float *gb, void *ws,
+                           size_t ws_bytes, const ddcn_geom *g, void *stream)
+{
+    TRY(check_geom(g));
+    TRY(check_ws(g, ws, ws_bytes));
+    hipStream_t s = (hipStream_t)stream;
+    float *col = (float *)ws;
+    TRY(launch_gemm_gcol(weight, gout, col, *g, s));
+    TRY(launch_col2im_coord(col, x, offset, mask, gx, goff, gmask, *g, s));
+    TRY(launch_im2col(x, offset, mask, col, *g, s));
+    TRY(launch_gemm_gweight(gout, col, gw, *g, s));
+    if (gb) TRY(launch_bias_grad(gout, gb, *g, s));
+    return DDCN_OK;
+}
+
+int ddcn_deform_conv_forward_f32(const float *x, const float *weight, const float *bias, const float *offset,
+                                 float *out, void *workspace, size_t workspace_bytes, const ddcn_geom *g,
+                                 void *stream)
+{
+    REQUIRE(x); REQUIRE(weight); REQUIRE(offset); REQUIRE(out);
+    return deform_forward(x, weight, bias, offset, nullptr, out, workspace, workspace_bytes, g, stream);
+}
+
+int ddcn_deform_conv_backward_f32(const float *x, const float *weight, const float *offset, const float *grad_out,
+                                  float *gx, float *goff, float *gw, float *gb, void *workspace,
+                                  size_t workspace_bytes, const ddcn_geom *g, void *stream)
+{
+    REQUIRE(x); REQUIRE(weight); REQUIRE(offset); REQUIRE(grad_out); REQUIRE(gx); REQUIRE(goff); REQUIRE(gw);
+    return deform_backward(x, weight, offset, nullptr, grad_out, gx, goff, nullptr, gw, gb, workspace,
+                           workspace_bytes, g, stream);
+}
+
+int ddcn_modulated_deform_conv_forward_f32(const float *x, const float *weight, const float *bias,
+                                           const float *offset, const float *mask, float *out, void *workspace,
+                                           size_t workspace_bytes, const ddcn_geom *g, void *stream)
+{
+    REQUIRE(x); REQUIRE(weight); REQUIRE(offset); REQUIRE(mask); REQUIRE(out);
+    return deform_forward(x, weight, bias, offset, mask, out, workspace, workspace_bytes, g, stream);
+}
+
+int ddcn_modulated_deform_conv_backward_f32(const float *x, const float *weight, const float *offset,
+                                            const float *mask, const float *grad_out, float *gx, float *goff,
+                                            float *gmask, float *gw, float *gb, void *workspace,
+                                            size_t workspace_bytes, const ddcn_geom *g, void *stream)
+{
+    REQUIRE(x); REQUIRE(weight); REQUIRE(offset); REQUIRE(mask); REQUIRE(grad_out);
+    REQUIRE(gx); REQUIRE(goff); REQUIRE(gmask); REQUIRE(gw);
+    return deform_backward(x, weight, offset, mask, grad_out, gx, goff, gmask, gw, gb, workspace, workspace_bytes,
+                           g, stream);
+}
+
+int ddcn_depthaware_conv_forward_f32(const float *x, const float *depth, const float *weight, const float *bias,
+                                     float *out, void *workspace, size_t workspace_bytes, const ddcn_geom *g,
+                                     void *stream)
+{
+    REQUIRE(x); REQUIRE(depth); REQUIRE(weight); REQUIRE(out);
+    TRY(check_geom(g));
+    TRY(check_ws(g, workspace, workspace_bytes));
+    hipStream_t s = (hipStream_t)stream;
+    float *col = (float *)workspace;
+    TRY(launch_depthaware_im2col(x, depth, col, *g, s));
+    TRY(launch_gemm_out(weight, col, bias, out, *g, s));
+    return DDCN_OK;
+}
+
+int ddcn_depthaware_conv_backward_f32(const float *x, const float *depth, const float *weight,
+                                      const float *grad_out, float *gx, float *gw, float *gb, void *workspace,
+                                      size_t workspace_bytes, const ddcn_geom *g, void *stream)
+{
+    REQUIRE(x); REQUIRE(depth); REQUIRE(weight); REQUIRE(grad_out); REQUIRE(gx); REQUIRE(gw);
+    TRY(check_geom(g));
+    TRY(check_ws(g, workspace, workspace_bytes));
+    hipStream_t s = (hipStream_t)stream;
+    float *col = (float *)workspace;
+    TRY(launch_gemm_gcol(weight, grad_out, col, *g, s));
+    TRY(launch_depthaware_col2im(col, depth, gx, *g, s));
+    TRY(launch_depthaware_im2col(x, depth, col, *g, s));
+    TRY(launch_gemm_gweight(grad_out, col, gw, *g, s));
+    if (gb) TRY(launch_bias_grad(grad_out, gb, *g, s));
+    return DDCN_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,52 @@
+// Internal header shared by the HIP translation units of libddcn_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+#include "../../include/ddcn_hip.h"
+
+namespace ddcn {
+
+// Sets the calling thread's detail message and returns rc (so callers can `return fail(...)`).
+int fail(int rc, const char *fmt, ...);
+int check_launch(const char *what);
+
+static inline size_t round_up(size_t v, size_t m) { return (v + m - 1) / m * m; }
+
+struct Dims {
+    int K2, P, Ktot, Kg, Cg, Cog, cpg;
+    long ld;  // columns leading dimension
+};
+
+static inline Dims dims_of(const ddcn_geom &g)
+{
+    Dims d;
+    d.K2 = g.kh * g.kw;
+    d.P = g.Ho * g.Wo;
+    d.Ktot = g.C * d.K2;
+    d.Cg = g.C / g.groups;
+    d.Cog = g.Co / g.groups;
+    d.Kg = d.Cg * d.K2;
+    d.cpg = g.C / g.dg;
+    d.ld = (long)round_up((size_t)d.P, 32);
+    return d;
+}
+
+// ---- launchers implemented in the .hip files (all asynchronous on `stream`) ----
+int launch_im2col(const float *x, const float *offset, const float *mask, float *col, const ddcn_geom &g,
+                  hipStream_t stream);
+int launch_col2im_coord(const float *gcol, const float *x, const float *offset, const float *mask, float *gx,
+                        float *goff, float *gmask, const ddcn_geom &g, hipStream_t stream);
+int launch_depthaware_im2col(const float *x, const float *depth, float *col, const ddcn_geom &g,
+                             hipStream_t stream);
+int launch_depthaware_col2im(const float *gcol, const float *depth, float *gx, const ddcn_geom &g,
+                             hipStream_t stream);
+int launch_bias_grad(const float *gout, float *gb, const ddcn_geom &g, hipStream_t stream);
+
+int launch_gemm_out(const float *weight, const float *col, const float *bias, float *out, const ddcn_geom &g,
+                    hipStream_t stream);
+int launch_gemm_gcol(const float *weight, const float *gout, float *gcol, const ddcn_geom &g, hipStream_t stream);
+int launch_gemm_gweight(const float *gout, const float *col, float *gw, const ddcn_geom &g, hipStream_t stream);
+
+}  // namespace ddcn

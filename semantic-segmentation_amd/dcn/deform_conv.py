@@ -1,0 +1,446 @@
+"""Python boundary of the DDCN operator: the three autograd.Functions, their functional aliases and
+the six nn.Modules of the reference's `detseg/ops/dcn/deform_conv.py` (PY below), with the same
+names, positional argument order, defaults, saved tensors, gradient tuples and state-dict keys.
+
+Where the reference called its pybind CUDA extension (PY:41-45, 58-63, 113-117, 131-136, 182-186,
+198-203) this file calls the C ABI of libddcn_hip.so (include/ddcn_hip.h) on torch's current HIP
+stream.  CPU tensors raise NotImplementedError exactly as PY:33-34, 51-52 do; there is no fallback.
+
+Deliberate deviations from the reference:
+  C1  DeformConvPack.forward passes self.bias (PY:296-297 dropped it, shifting every argument).
+  C2  ModulatedDeformConvPack.conv_offset_mask gets dilation=self.dilation (PY:352-359 omitted it, so
+      dilated layers produced a wrongly sized offset map that the CUDA kernel mis-indexed silently).
+  C4  offset / mask / depth shapes are checked and made contiguous (the reference read garbage).
+  C5  kernels run on torch's current stream, not the legacy default stream.
+  C6  the columns scratch is torch.empty (never zero-filled) and comes from the caching allocator.
+"""
+import math
+
+import torch
+import torch.nn as nn
+from torch.autograd import Function
+from torch.autograd.function import once_differentiable
+from torch.nn.modules.utils import _pair
+
+from . import _lib
+
+
+def _geom(input, weight, stride, padding, dilation, groups, deformable_groups):
+    if input.dim() != 4:
+        raise RuntimeError("4D input tensor expected but got: %d" % input.dim())
+    if weight.dim() != 4:
+        raise RuntimeError("4D weight tensor (nOutputPlane,nInputPlane,kH,kW) expected, but got: %d" % weight.dim())
+    n, c, h, w = input.shape
+    co, _, kh, kw = weight.shape
+    if c != weight.shape[1] * groups:
+        raise RuntimeError("Input shape and kernel channels wont match: (%d vs %d)." % (c, weight.shape[1] * groups))
+    g = _lib.Geom(n, c, h, w, co, kh, kw, stride, stride, padding, padding, dilation, dilation, groups,
+                  deformable_groups, 0, 0)
+    _lib.check(_lib.lib().ddcn_infer_output(g))
+    _lib.check(_lib.lib().ddcn_check_geom(g))
+    return g
+
+
+def _check_f32_cuda(name, t):
+    if not t.is_cuda:
+        raise NotImplementedError
+    if t.dtype != torch.float32:
+        raise RuntimeError("ddcn: %s must be float32 (got %s); fp32 is the only dtype built so far" % (name, t.dtype))
+
+
+def _contig(name, t):
+    # deform_conv_cuda.cpp:179-180: input and weight must be contiguous
+    if not t.is_contiguous():
+        raise RuntimeError("%s tensor has to be contiguous" % name)
+
+
+def _workspace(input, g):
+    nbytes = _lib.lib().ddcn_workspace_bytes(g)
+    return torch.empty(nbytes // 4, dtype=torch.float32, device=input.device), nbytes
+
+
+def _expect_shape(name, t, shape):
+    if tuple(t.shape) != tuple(shape):
+        raise RuntimeError("invalid shape of %s, expected %s but got %s" % (name, tuple(shape), tuple(t.shape)))
+
+
+def _infer_shape(ctx, input, weight):
+    """(N, Co, Ho, Wo) with floor division -- PY:71-80, 143-153, 210-220."""
+    kh, kw = weight.shape[2:4]
+    ho = (input.size(2) + 2 * ctx.padding - (ctx.dilation * (kh - 1) + 1)) // ctx.stride + 1
+    wo = (input.size(3) + 2 * ctx.padding - (ctx.dilation * (kw - 1) + 1)) // ctx.stride + 1
+    return input.size(0), weight.size(0), ho, wo
+
+
+class DeformConvFunction(Function):
+
+    @staticmethod
+    def forward(ctx,
+                input,
+                offset,
+                weight,
+                bias=None,
+                stride=1,
+                padding=0,
+                dilation=1,
+                groups=1,
+                deformable_groups=1):
+        ctx.stride = stride
+        ctx.padding = padding
+        ctx.dilation = dilation
+        ctx.groups = groups
+        ctx.deformable_groups = deformable_groups
+        ctx.with_bias = bias is not None
+        if not ctx.with_bias:
+            bias = input.new_empty(1)  # fake tensor
+        if not input.is_cuda:
+            raise NotImplementedError
+        for name, t in (("input", input), ("offset", offset), ("weight", weight), ("bias", bias)):
+            _check_f32_cuda(name, t)
+        _contig("input", input)
+        _contig("weight", weight)
+        g = _geom(input, weight, stride, padding, dilation, groups, deformable_groups)
+        k2 = g.kh * g.kw
+        _expect_shape("offset", offset, (g.N, deformable_groups * 2 * k2, g.Ho, g.Wo))
+        offset = offset.contiguous()
+        if weight.requires_grad or offset.requires_grad \
+                or input.requires_grad:
+            ctx.save_for_backward(input, offset, weight, bias)
+        output = input.new_empty(
+            DeformConvFunction._infer_shape(ctx, input, weight))
+        ws, ws_bytes = _workspace(input, g)
+        with torch.cuda.device(input.device):
+            _lib.check(_lib.lib().ddcn_deform_conv_forward_f32(
+                _lib.ptr(input), _lib.ptr(weight), _lib.ptr(bias) if ctx.with_bias else None, _lib.ptr(offset),
+                _lib.ptr(output), _lib.ptr(ws), ws_bytes, g, _lib.current_stream(input.device)))
+        return output
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, grad_output):
+        if not grad_output.is_cuda:
+            raise NotImplementedError
+        input, offset, weight, bias = ctx.saved_tensors
+        grad_output = grad_output.contiguous()
+        grad_input = torch.zeros_like(input)
+        grad_offset = torch.zeros_like(offset)
+        grad_weight = torch.zeros_like(weight)
+        grad_bias = torch.zeros_like(bias)
+        g = _geom(input, weight, ctx.stride, ctx.padding, ctx.dilation, ctx.groups, ctx.deformable_groups)
+        _expect_shape("grad_output", grad_output, (g.N, g.Co, g.Ho, g.Wo))
+        ws, ws_bytes = _workspace(input, g)
+        with torch.cuda.device(input.device):
+            _lib.check(_lib.lib().ddcn_deform_conv_backward_f32(
+                _lib.ptr(input), _lib.ptr(weight), _lib.ptr(offset), _lib.ptr(grad_output), _lib.ptr(grad_input),
+                _lib.ptr(grad_offset), _lib.ptr(grad_weight), _lib.ptr(grad_bias) if ctx.with_bias else None,
+                _lib.ptr(ws), ws_bytes, g, _lib.current_stream(input.device)))
+        if not ctx.with_bias:
+            grad_bias = None
+
+        return (grad_input, grad_offset, grad_weight, grad_bias,
+                None, None, None, None, None)
+
+    _infer_shape = staticmethod(_infer_shape)
+
+
+class ModulatedDeformConvFunction(Function):
+
+    @staticmethod
+    def forward(ctx,
+                input,
+                offset,
+                mask,
+                weight,
+                bias=None,
+                stride=1,
+                padding=0,
+                dilation=1,
+                groups=1,
+                deformable_groups=1):
+        ctx.stride = stride
+        ctx.padding = padding
+        ctx.dilation = dilation
+        ctx.groups = groups
+        ctx.deformable_groups = deformable_groups
+        ctx.with_bias = bias is not None
+        if not ctx.with_bias:
+            bias = input.new_empty(1)  # fake tensor
+        if not input.is_cuda:
+            raise NotImplementedError
+        for name, t in (("input", input), ("offset", offset), ("mask", mask), ("weight", weight), ("bias", bias)):
+            _check_f32_cuda(name, t)
+        _contig("input", input)
+        _contig("weight", weight)
+        g = _geom(input, weight, stride, padding, dilation, groups, deformable_groups)
+        k2 = g.kh * g.kw
+        _expect_shape("offset", offset, (g.N, deformable_groups * 2 * k2, g.Ho, g.Wo))
+        _expect_shape("mask", mask, (g.N, deformable_groups * k2, g.Ho, g.Wo))
+        offset = offset.contiguous()
+        mask = mask.contiguous()
+        if weight.requires_grad or mask.requires_grad or offset.requires_grad \
+                or input.requires_grad:
+            ctx.save_for_backward(input, offset, mask, weight, bias)
+        output = input.new_empty(
+            ModulatedDeformConvFunction._infer_shape(ctx, input, weight))
+        ws, ws_bytes = _workspace(input, g)
+        with torch.cuda.device(input.device):
+            _lib.check(_lib.lib().ddcn_modulated_deform_conv_forward_f32(
+                _lib.ptr(input), _lib.ptr(weight), _lib.ptr(bias) if ctx.with_bias else None, _lib.ptr(offset),
+                _lib.ptr(mask), _lib.ptr(output), _lib.ptr(ws), ws_bytes, g, _lib.current_stream(input.device)))
+        return output
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, grad_output):
+        if not grad_output.is_cuda:
+            raise NotImplementedError
+        input, offset, mask, weight, bias = ctx.saved_tensors
+        grad_output = grad_output.contiguous()
+        grad_input = torch.zeros_like(input)
+        grad_offset = torch.zeros_like(offset)
+        grad_mask = torch.zeros_like(mask)
+        grad_weight = torch.zeros_like(weight)
+        grad_bias = torch.zeros_like(bias)
+        g = _geom(input, weight, ctx.stride, ctx.padding, ctx.dilation, ctx.groups, ctx.deformable_groups)
+        _expect_shape("grad_output", grad_output, (g.N, g.Co, g.Ho, g.Wo))
+        ws, ws_bytes = _workspace(input, g)
+        with torch.cuda.device(input.device):
+            _lib.check(_lib.lib().ddcn_modulated_deform_conv_backward_f32(
+                _lib.ptr(input), _lib.ptr(weight), _lib.ptr(offset), _lib.ptr(mask), _lib.ptr(grad_output),
+                _lib.ptr(grad_input), _lib.ptr(grad_offset), _lib.ptr(grad_mask), _lib.ptr(grad_weight),
+                _lib.ptr(grad_bias) if ctx.with_bias else None, _lib.ptr(ws), ws_bytes, g,
+                _lib.current_stream(input.device)))
+        if not ctx.with_bias:
+            grad_bias = None
+
+        return (grad_input, grad_offset, grad_mask, grad_weight, grad_bias,
+                None, None, None, None, None)
+
+    _infer_shape = staticmethod(_infer_shape)
+
+
+class DepthawareConvFunction(Function):
+
+    @staticmethod
+    def forward(ctx,
+                input,
+                depth,
+                weight,
+                bias=None,
+                stride=1,
+                padding=0,
+                dilation=1,
+                groups=1):
+        ctx.stride = stride
+        ctx.padding = padding
+        ctx.dilation = dilation
+        ctx.groups = groups
+        ctx.with_bias = bias is not None
+        if not ctx.with_bias:
+            bias = input.new_empty(1)  # fake tensor
+        if not input.is_cuda:
+            raise NotImplementedError
+        for name, t in (("input", input), ("depth", depth), ("weight", weight), ("bias", bias)):
+            _check_f32_cuda(name, t)
+        _contig("input", input)
+        _contig("weight", weight)
+        g = _geom(input, weight, stride, padding, dilation, groups, 1)
+        _expect_shape("depth", depth, (g.N, 1, g.H, g.W))
+        depth = depth.contiguous()
+        if weight.requires_grad or input.requires_grad:
+            ctx.save_for_backward(input, depth, weight, bias)
+        output = input.new_empty(
+            DepthawareConvFunction._infer_shape(ctx, input, weight))
+        ws, ws_bytes = _workspace(input, g)
+        with torch.cuda.device(input.device):
+            _lib.check(_lib.lib().ddcn_depthaware_conv_forward_f32(
+                _lib.ptr(input), _lib.ptr(depth), _lib.ptr(weight), _lib.ptr(bias) if ctx.with_bias else None,
+                _lib.ptr(output), _lib.ptr(ws), ws_bytes, g, _lib.current_stream(input.device)))
+        return output
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, grad_output):
+        if not grad_output.is_cuda:
+            raise NotImplementedError
+        input, depth, weight, bias = ctx.saved_tensors
+        grad_output = grad_output.contiguous()
+        grad_input = torch.zeros_like(input)
+        grad_weight = torch.zeros_like(weight)
+        grad_bias = torch.zeros_like(bias)
+        g = _geom(input, weight, ctx.stride, ctx.padding, ctx.dilation, ctx.groups, 1)
+        _expect_shape("grad_output", grad_output, (g.N, g.Co, g.Ho, g.Wo))
+        ws, ws_bytes = _workspace(input, g)
+        with torch.cuda.device(input.device):
+            _lib.check(_lib.lib().ddcn_depthaware_conv_backward_f32(
+                _lib.ptr(input), _lib.ptr(depth), _lib.ptr(weight), _lib.ptr(grad_output), _lib.ptr(grad_input),
+                _lib.ptr(grad_weight), _lib.ptr(grad_bias) if ctx.with_bias else None, _lib.ptr(ws), ws_bytes, g,
+                _lib.current_stream(input.device)))
+        if not ctx.with_bias:
+            grad_bias = None
+
+        # one gradient slot per forward input (the reference returned a surplus trailing None, PY:207-208)
+        return (grad_input, None, grad_weight, grad_bias,
+                None, None, None, None)
+
+    _infer_shape = staticmethod(_infer_shape)
+
+
+deform_conv = DeformConvFunction.apply
+modulated_deform_conv = ModulatedDeformConvFunction.apply
+depthaware_conv = DepthawareConvFunction.apply
+
+
+class _DcnConvBase(nn.Module):
+    """Parameter holder shared by the three plain modules: weight ~ U(-1/sqrt(Ci*K2), +) and zero bias
+    (PY:261-268, 332-339, 410-415); attribute names and state-dict keys (`weight`, `bias`) as in the reference."""
+
+    _default_bias = False
+
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, dilation=1, groups=1,
+                 deformable_groups=1, bias=None):
+        super().__init__()
+        if bias is None:
+            bias = self._default_bias
+        self.in_channels = in_channels
+        self.out_channels = out_channels
+        self.kernel_size = _pair(kernel_size)
+        self.stride = stride
+        self.padding = padding
+        self.dilation = dilation
+        self.groups = groups
+        self.deformable_groups = deformable_groups
+        self.with_bias = bias
+        self.weight = nn.Parameter(torch.Tensor(out_channels, in_channels // groups, *self.kernel_size))
+        if bias:
+            self.bias = nn.Parameter(torch.Tensor(out_channels))
+        else:
+            self.register_parameter('bias', None)
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        fan = self.in_channels * self.kernel_size[0] * self.kernel_size[1]
+        stdv = 1. / math.sqrt(fan)
+        self.weight.data.uniform_(-stdv, stdv)
+        if self.bias is not None:
+            self.bias.data.zero_()
+
+    def _offset_conv(self, in_channels, out_channels):
+        """3x3 (kernel-sized) plain conv producing offsets / masks at the op's own output resolution."""
+        return nn.Conv2d(in_channels, out_channels, kernel_size=self.kernel_size, stride=_pair(self.stride),
+                         padding=_pair(self.padding), dilation=_pair(self.dilation), bias=True)
+
+
+class DeformConv(_DcnConvBase):
+    """PY:228-272.  forward(x, offset); bias defaults to False."""
+    _default_bias = False
+
+    def forward(self, x, offset):
+        return deform_conv(x, offset, self.weight, self.bias, self.stride, self.padding,
+                           self.dilation, self.groups, self.deformable_groups)
+
+
+class DeformConvPack(DeformConv):
+
+    def __init__(self, *args, **kwargs):
+        super(DeformConvPack, self).__init__(*args, **kwargs)
+
+        k2 = self.kernel_size[0] * self.kernel_size[1]
+        # C2-style fix: the offset conv follows the op's dilation (PY:280-287 omitted it)
+        self.conv_offset = self._offset_conv(self.in_channels, self.deformable_groups * 2 * k2)
+        self.init_offset()
+
+    def init_offset(self):
+        self.conv_offset.weight.data.zero_()
+        self.conv_offset.bias.data.zero_()
+
+    def forward(self, x):
+        offset = self.conv_offset(x)
+        # C1: the reference omitted self.bias here (PY:296-297)
+        return deform_conv(x, offset, self.weight, self.bias, self.stride, self.padding,
+                           self.dilation, self.groups, self.deformable_groups)
+
+
+class ModulatedDeformConv(_DcnConvBase):
+    """PY:300-344.  forward(x, offset, mask); bias defaults to True."""
+    _default_bias = True
+
+    def forward(self, x, offset, mask):
+        return modulated_deform_conv(x, offset, mask, self.weight, self.bias,
+                                     self.stride, self.padding, self.dilation,
+                                     self.groups, self.deformable_groups)
+
+
+class ModulatedDeformConvPack(ModulatedDeformConv):
+
+    def __init__(self, *args, **kwargs):
+        super(ModulatedDeformConvPack, self).__init__(*args, **kwargs)
+
+        k2 = self.kernel_size[0] * self.kernel_size[1]
+        # C2: dilation added (PY:352-359 omitted it)
+        self.conv_offset_mask = self._offset_conv(self.in_channels, self.deformable_groups * 3 * k2)
+        self.init_offset()
+
+    def init_offset(self):
+        self.conv_offset_mask.weight.data.zero_()
+        self.conv_offset_mask.bias.data.zero_()
+        self.conv_offset_mask.lr_mult = 0.1
+
+    def forward(self, x):
+        out = self.conv_offset_mask(x)
+        o1, o2, mask = torch.chunk(out, 3, dim=1)
+        offset = torch.cat((o1, o2), dim=1)
+        mask = torch.sigmoid(mask)
+        self.offset, self.mask = offset, mask
+        return modulated_deform_conv(x, offset, mask, self.weight, self.bias,
+                                     self.stride, self.padding, self.dilation,
+                                     self.groups, self.deformable_groups)
+
+
+class DepthawareConv(_DcnConvBase):
+    """PY:378-419.  forward(x, depth); bias defaults to False; `deformable_groups` is accepted and unused."""
+    _default_bias = False
+
+    def reset_parameters(self):
+        # PY:410-415 leaves a requested bias uninitialised; zero it here
+        super().reset_parameters()
+
+    def forward(self, x, depth):
+        return depthaware_conv(x, depth, self.weight, self.bias, self.stride, self.padding,
+                               self.dilation, self.groups)
+
+
+class DepthDeformConvPack(ModulatedDeformConv):
+    """The DDCN layer (PY:422-463): offsets from cat(x, depth), mask from a deformable conv over depth."""
+
+    def __init__(self, *args, **kwargs):
+        assert 'depth_channels' in kwargs
+        depth_channels = kwargs.pop('depth_channels')
+        super(DepthDeformConvPack, self).__init__(*args, **kwargs)
+
+        k2 = self.kernel_size[0] * self.kernel_size[1]
+        self.conv_offset = self._offset_conv(self.in_channels + depth_channels, self.deformable_groups * 2 * k2)
+        # positional ctor in the reference -> deformable_groups stays 1 for the mask branch (C3)
+        self.conv_mask = DeformConv(depth_channels, self.deformable_groups * k2, kernel_size=self.kernel_size,
+                                    stride=self.stride, padding=self.padding, dilation=self.dilation, bias=True)
+        self.init_offset()
+
+    def init_offset(self):
+        self.conv_offset.weight.data.zero_()
+        self.conv_offset.bias.data.zero_()
+        self.conv_mask.weight.data.zero_()
+        self.conv_mask.bias.data.zero_()
+        self.conv_offset.lr_mult = 0.1
+        self.conv_mask.lr_mult = 0.1
+
+    def forward(self, x, depth):
+        offset = self.conv_offset(torch.cat((x, depth), dim=1))
+        # C3: conv_mask is built with deformable_groups=1 (PY:438-446), so the reference kernel only ever
+        # read the first 2*K2 offset channels of each image; state that explicitly instead of by pointer luck
+        k2x2 = 2 * self.kernel_size[0] * self.kernel_size[1]
+        mask_offset = offset if self.deformable_groups == 1 else offset[:, :k2x2].contiguous()
+        mask = torch.sigmoid(self.conv_mask(depth, mask_offset))
+        self.offset, self.mask = offset, mask
+        return modulated_deform_conv(x, offset, mask, self.weight, self.bias,
+                                     self.stride, self.padding, self.dilation,
+                                     self.groups, self.deformable_groups)

@@ -1,0 +1,354 @@
+"""GPU parity tests proper: the HIP path (through the C ABI) against the CPU oracle and the golden fixtures.
+
+Bar (BASELINE.json north_star): fp32 forward rel-err <= 1e-5, backward <= 1e-4 (atomic reordering), with
+rel-err := max|a-b| / max|b| per tensor against the fp64 oracle evaluated on the same fp32-rounded inputs.
+"""
+import ctypes
+import importlib
+
+import numpy as np
+import pytest
+import torch
+
+import cases
+from helpers import BWD_TOL, FWD_TOL, load_golden
+from oracle import ddcn_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+if torch.cuda.is_available():
+    pkg = importlib.import_module("semantic-segmentation_amd")
+    _lib = importlib.import_module("semantic-segmentation_amd.dcn._lib")
+DEV = "cuda:0"
+
+
+def _t(a, grad=False):
+    if a is None:
+        return None
+    t = torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(DEV)
+    return t.requires_grad_(True) if grad else t
+
+
+def _r32(inp):
+    return {k: (None if v is None else v.astype(np.float32).astype(np.float64)) for k, v in inp.items()}
+
+
+def _run_hip(c, inp):
+    x, off, w = _t(inp["x"], True), _t(inp["offset"], True), _t(inp["weight"], True)
+    m = _t(inp.get("mask"), True) if c["modulated"] else None
+    b = _t(inp.get("bias"), True) if c["bias"] else None
+    if c["modulated"]:
+        out = pkg.modulated_deform_conv(x, off, m, w, b, c["stride"], c["pad"], c["dil"], c["groups"], c["dg"])
+    else:
+        out = pkg.deform_conv(x, off, w, b, c["stride"], c["pad"], c["dil"], c["groups"], c["dg"])
+    out.backward(_t(inp["gout"]))
+    torch.cuda.synchronize()
+    g = lambda t: None if t is None else t.grad.cpu().numpy()
+    return out.detach().cpu().numpy(), dict(gx=g(x), goff=g(off), gmask=g(m), gw=g(w), gb=g(b))
+
+
+def _assert_case(c, out, grads, exp):
+    assert cases.relerr(out, exp["out"]) <= FWD_TOL, ("out", cases.relerr(out, exp["out"]))
+    for k in ("gx", "goff", "gw"):
+        assert cases.relerr(grads[k], exp[k]) <= BWD_TOL, (k, cases.relerr(grads[k], exp[k]))
+    if c["modulated"]:
+        assert cases.relerr(grads["gmask"], exp["gmask"]) <= BWD_TOL, "gmask"
+    if c["bias"]:
+        assert cases.relerr(grads["gb"], exp["gb"]) <= BWD_TOL, "gb"
+
+
+def test_extension_is_the_hip_library():
+    assert _lib.lib().ddcn_version() == 100
+    assert "libddcn_hip.so" in _lib.LIB_PATH
+
+
+@pytest.mark.parametrize("c", cases.SMALL_CASES, ids=lambda c: c["name"])
+def test_hip_matches_golden_fixtures(c):
+    g = load_golden(c["name"])
+    out, grads = _run_hip(c, g)
+    _assert_case(c, out, grads, g)
+
+
+@pytest.mark.parametrize("c", cases.MEDIUM_CASES, ids=lambda c: c["name"])
+def test_hip_matches_oracle_medium(c):
+    inp = _r32(cases.make_inputs(c))
+    kw = cases.kwargs(c)
+    exp = dict(out=orc.deform_forward(inp["x"], inp["offset"], inp["mask"], inp["weight"], inp["bias"], **kw))
+    exp["gx"], exp["goff"], exp["gmask"], exp["gw"], exp["gb"] = orc.deform_backward(
+        inp["x"], inp["offset"], inp["mask"], inp["weight"], inp["gout"], c["bias"], **kw)
+    out, grads = _run_hip(c, inp)
+    _assert_case(c, out, grads, exp)
+
+
+@pytest.mark.parametrize("c", cases.DEPTHAWARE_CASES, ids=lambda c: c["name"])
+def test_hip_depthaware_matches_golden(c):
+    g = load_golden(c["name"])
+    x, w = _t(g["x"], True), _t(g["weight"], True)
+    b = _t(g.get("bias"), True) if c["bias"] else None
+    out = pkg.depthaware_conv(x, _t(g["depth"]), w, b, c["stride"], c["pad"], c["dil"], c["groups"])
+    out.backward(_t(g["gout"]))
+    assert cases.relerr(out.detach().cpu().numpy(), g["out"]) <= FWD_TOL
+    assert cases.relerr(x.grad.cpu().numpy(), g["gx"]) <= BWD_TOL
+    assert cases.relerr(w.grad.cpu().numpy(), g["gw"]) <= BWD_TOL
+    if c["bias"]:
+        assert cases.relerr(b.grad.cpu().numpy(), g["gb"]) <= BWD_TOL
+
+
+# ---------------------------------------------------------------- stage level, straight through the C ABI
+def _geom(c):
+    Ho, Wo, _ = cases.geometry(c)
+    return _lib.Geom(c["N"], c["Ci"], c["H"], c["W"], c["Co"], c["kh"], c["kw"], c["stride"], c["stride"], c["pad"],
+                     c["pad"], c["dil"], c["dil"], c["groups"], c["dg"], Ho, Wo)
+
+
+@pytest.mark.parametrize("c", [cases.SMALL_CASES[3], cases.SMALL_CASES[12], cases.MEDIUM_CASES[0],
+                               cases.MEDIUM_CASES[2]], ids=lambda c: c["name"])
+def test_stage_im2col_and_scatter_against_oracle(c):
+    inp = _r32(cases.make_inputs(c))
+    g = _geom(c)
+    L = _lib.lib()
+    K2, P = c["kh"] * c["kw"], g.Ho * g.Wo
+    ld = L.ddcn_col_ld(g)
+    x, off, msk = _t(inp["x"]), _t(inp["offset"]), _t(inp["mask"])
+    col = torch.full((c["N"], c["Ci"] * K2, ld), float("nan"), device=DEV)
+    s = _lib.current_stream(torch.device(DEV))
+    _lib.check(L.ddcn_im2col_f32(_lib.ptr(x), _lib.ptr(off), _lib.ptr(msk), _lib.ptr(col), g, s))
+    torch.cuda.synchronize()
+    got = col[:, :, :P].cpu().numpy()
+    for n in range(c["N"]):
+        exp = orc.im2col(inp["x"][n], inp["offset"][n], inp["mask"][n], c["kh"], c["kw"], c["stride"], c["pad"],
+                         c["dil"], c["dg"])
+        assert cases.relerr(got[n], exp) <= FWD_TOL
+    # scatter stage: feed a random gcol
+    rng = np.random.default_rng(99)
+    gcol = rng.standard_normal((c["N"], c["Ci"] * K2, P)).astype(np.float32)
+    gcol_d = torch.zeros((c["N"], c["Ci"] * K2, ld), device=DEV)
+    gcol_d[:, :, :P] = torch.from_numpy(gcol).to(DEV)
+    gx = torch.zeros_like(x)
+    goff = torch.full_like(off, 7.0)     # must be overwritten
+    gmask = torch.full_like(msk, 7.0)
+    _lib.check(L.ddcn_col2im_coord_f32(_lib.ptr(gcol_d), _lib.ptr(x), _lib.ptr(off), _lib.ptr(msk), _lib.ptr(gx),
+                                       _lib.ptr(goff), _lib.ptr(gmask), g, s))
+    torch.cuda.synchronize()
+    for n in range(c["N"]):
+        egx = orc.col2im(gcol[n].astype(np.float64), inp["offset"][n], inp["mask"][n], c["Ci"], c["H"], c["W"],
+                         c["kh"], c["kw"], c["stride"], c["pad"], c["dil"], c["dg"])
+        egoff, egmask = orc.col2im_coord(gcol[n].astype(np.float64), inp["x"][n], inp["offset"][n], inp["mask"][n],
+                                         c["kh"], c["kw"], c["stride"], c["pad"], c["dil"], c["dg"])
+        assert cases.relerr(gx[n].cpu().numpy(), egx) <= BWD_TOL
+        assert cases.relerr(goff[n].cpu().numpy(), egoff) <= BWD_TOL
+        assert cases.relerr(gmask[n].cpu().numpy(), egmask) <= BWD_TOL
+
+
+def test_stage_gemms_against_fp64_matmul():
+    c = cases.MEDIUM_CASES[2]   # Ci=128, Co=136 (M edge), P=625 (N edge), groups 1
+    g = _geom(c)
+    L = _lib.lib()
+    K2, P = 9, g.Ho * g.Wo
+    K = c["Ci"] * K2
+    ld = L.ddcn_col_ld(g)
+    rng = np.random.default_rng(5)
+    w = rng.standard_normal((c["Co"], K)).astype(np.float32)
+    col = rng.standard_normal((c["N"], K, P)).astype(np.float32)
+    gout = rng.standard_normal((c["N"], c["Co"], P)).astype(np.float32)
+    bias = rng.standard_normal((c["Co"],)).astype(np.float32)
+    col_d = torch.full((c["N"], K, ld), float("nan"), device=DEV)
+    col_d[:, :, :P] = torch.from_numpy(col).to(DEV)
+    w_d, gout_d, bias_d = _t(w), _t(gout), _t(bias)
+    s = _lib.current_stream(torch.device(DEV))
+    out = torch.empty((c["N"], c["Co"], P), device=DEV)
+    _lib.check(L.ddcn_gemm_out_f32(_lib.ptr(w_d), _lib.ptr(col_d), _lib.ptr(bias_d), _lib.ptr(out), g, s))
+    exp = np.einsum("ok,nkp->nop", w.astype(np.float64), col.astype(np.float64)) + bias.reshape(1, -1, 1)
+    assert cases.relerr(out.cpu().numpy(), exp) <= FWD_TOL
+    gcol = torch.full((c["N"], K, ld), float("nan"), device=DEV)
+    _lib.check(L.ddcn_gemm_gcol_f32(_lib.ptr(w_d), _lib.ptr(gout_d), _lib.ptr(gcol), g, s))
+    exp = np.einsum("ok,nop->nkp", w.astype(np.float64), gout.astype(np.float64))
+    assert cases.relerr(gcol[:, :, :P].cpu().numpy(), exp) <= FWD_TOL
+    gw = torch.ones((c["Co"], K), device=DEV)     # accumulate semantics: starts at 1
+    _lib.check(L.ddcn_gemm_gweight_f32(_lib.ptr(gout_d), _lib.ptr(col_d), _lib.ptr(gw), g, s))
+    exp = 1.0 + np.einsum("nop,nkp->ok", gout.astype(np.float64), col.astype(np.float64))
+    assert cases.relerr(gw.cpu().numpy(), exp) <= BWD_TOL
+    gb = torch.ones((c["Co"],), device=DEV)
+    _lib.check(L.ddcn_bias_grad_f32(_lib.ptr(gout_d), _lib.ptr(gb), g, s))
+    assert cases.relerr(gb.cpu().numpy(), 1.0 + gout.astype(np.float64).sum(axis=(0, 2))) <= BWD_TOL
+
+
+# ---------------------------------------------------------------- the reference's own self-tests, on the GPU
+def test_ref_selftest_zero_offset_equals_conv2d_gpu():
+    # detseg/ops/dcn/test.py:17-94 (a),(b)
+    torch.manual_seed(3)
+    pcn = torch.nn.Conv2d(4, 4, 3, stride=1, padding=1, dilation=1, groups=2).to(DEV)
+    for mod in (False, True):
+        cls = pkg.ModulatedDeformConv if mod else pkg.DeformConv
+        dcn = cls(4, 4, (3, 3), stride=1, padding=1, dilation=1, groups=2, deformable_groups=1, bias=True).to(DEV)
+        dcn.weight, dcn.bias = pcn.weight, pcn.bias
+        x = torch.randn(2, 4, 4, 4, device=DEV)
+        offset = torch.zeros(2, 18, 4, 4, device=DEV)
+        if mod:
+            out = dcn(x, offset, torch.sigmoid(torch.zeros(2, 9, 4, 4, device=DEV)) * 2)
+        else:
+            out = dcn(x, offset)
+        assert (out - pcn(x)).abs().max().item() < 1e-5
+
+
+def test_ref_selftest_identity_weights_gpu():
+    # detseg/ops/dcn/test.py:112-181 (c),(d)
+    torch.manual_seed(3)
+    groups = 2
+    for mod in (False, True):
+        cls = pkg.ModulatedDeformConv if mod else pkg.DeformConv
+        dcn = cls(4, 4, (3, 3), stride=1, padding=1, dilation=1, groups=groups, deformable_groups=1, bias=True).to(DEV)
+        with torch.no_grad():
+            dcn.weight.zero_()
+            dcn.bias.zero_()
+            oc = 4 // groups
+            for p in range(dcn.weight.shape[1]):
+                for q in range(4):
+                    if p == q % oc:
+                        dcn.weight[q, p, 1, 1] = 1.0
+        x = torch.randn(2, 4, 4, 4, device=DEV)
+        offset = torch.zeros(2, 18, 4, 4, device=DEV)
+        if mod:
+            out = dcn(x, offset, torch.sigmoid(torch.zeros(2, 9, 4, 4, device=DEV))) * 2
+        else:
+            out = dcn(x, offset)
+        assert (x - out).abs().max().item() < 1e-10
+
+
+# ---------------------------------------------------------------- DDCN layer and packs
+def test_ddcn_layer_forward_backward_matches_composition():
+    """DepthDeformConvPack == conv_offset -> DeformConv mask branch -> modulated op (deform_conv.py:457-463),
+    checked against the oracle evaluated on the layer's own offset / mask tensors."""
+    torch.manual_seed(0)
+    layer = pkg.DepthDeformConvPack(16, 16, 3, stride=1, padding=2, dilation=2, deformable_groups=1, bias=False,
+                                    depth_channels=8).to(DEV)
+    with torch.no_grad():   # non-trivial offsets and masks
+        layer.conv_offset.weight.normal_(0, 0.05)
+        layer.conv_offset.bias.normal_(0, 0.5)
+        layer.conv_mask.weight.normal_(0, 0.1)
+        layer.conv_mask.bias.normal_(0, 0.1)
+    x = torch.randn(2, 16, 19, 17, device=DEV, requires_grad=True)
+    depth = torch.randn(2, 8, 19, 17, device=DEV, requires_grad=True)
+    out = layer(x, depth)
+    out.sum().backward()
+    assert out.shape == (2, 16, 19, 17)
+    assert layer.offset.shape == (2, 18, 19, 17) and layer.mask.shape == (2, 9, 19, 17)
+    f64 = lambda t: t.detach().cpu().numpy().astype(np.float64)
+    # mask branch
+    emask_pre = orc.deform_forward(f64(depth), f64(layer.offset), None, f64(layer.conv_mask.weight),
+                                   f64(layer.conv_mask.bias), 1, 2, 2, 1, 1)
+    emask = 1.0 / (1.0 + np.exp(-emask_pre))
+    assert cases.relerr(f64(layer.mask), emask) <= FWD_TOL
+    eout = orc.deform_forward(f64(x), f64(layer.offset), f64(layer.mask), f64(layer.weight), None, 1, 2, 2, 1, 1)
+    assert cases.relerr(f64(out), eout) <= FWD_TOL
+    for p in (layer.weight, layer.conv_offset.weight, layer.conv_mask.weight, layer.conv_mask.bias):
+        assert p.grad is not None and torch.isfinite(p.grad).all() and p.grad.abs().max() > 0
+    assert torch.isfinite(x.grad).all() and torch.isfinite(depth.grad).all()
+
+
+def test_modulated_pack_dg4_dilated_and_deform_pack():
+    torch.manual_seed(1)
+    mp = pkg.ModulatedDeformConvPack(16, 8, 3, stride=1, padding=2, dilation=2, deformable_groups=4, bias=False).to(DEV)
+    with torch.no_grad():
+        mp.conv_offset_mask.weight.normal_(0, 0.05)
+    x = torch.randn(1, 16, 13, 11, device=DEV, requires_grad=True)
+    out = mp(x)
+    out.square().sum().backward()
+    f64 = lambda t: t.detach().cpu().numpy().astype(np.float64)
+    eout = orc.deform_forward(f64(x), f64(mp.offset), f64(mp.mask), f64(mp.weight), None, 1, 2, 2, 1, 4)
+    assert cases.relerr(f64(out), eout) <= FWD_TOL
+    dp = pkg.DeformConvPack(16, 8, 3, stride=2, padding=1, bias=True).to(DEV)   # C1: runs at all
+    y = dp(x.detach())
+    assert y.shape == (1, 8, 7, 6)
+    ref = torch.nn.functional.conv2d(x.detach(), dp.weight, dp.bias, stride=2, padding=1)   # zero-init offsets
+    assert (y - ref).abs().max().item() < 1e-4
+
+
+def test_error_behaviour_gpu():
+    x = torch.randn(2, 4, 5, 5, device=DEV)
+    w = torch.randn(4, 4, 3, 3, device=DEV)
+    with pytest.raises(RuntimeError, match="invalid shape of offset"):
+        pkg.deform_conv(x, torch.zeros(2, 18, 4, 4, device=DEV), w, None, 1, 1, 1, 1, 1)
+    with pytest.raises(RuntimeError, match="contiguous"):       # deform_conv_cuda.cpp:179
+        pkg.deform_conv(x.transpose(2, 3), torch.zeros(2, 18, 5, 5, device=DEV), w, None, 1, 1, 1, 1, 1)
+    with pytest.raises(RuntimeError, match="wont match"):       # deform_conv_cuda.cpp:196-198
+        pkg.deform_conv(x, torch.zeros(2, 18, 5, 5, device=DEV), w, None, 1, 1, 1, 2, 1)
+    with pytest.raises(RuntimeError, match="float32"):
+        pkg.deform_conv(x.double(), torch.zeros(2, 18, 5, 5, device=DEV).double(), w.double(), None, 1, 1, 1, 1, 1)
+    L = _lib.lib()
+    g = _lib.Geom(2, 4, 5, 5, 4, 3, 3, 1, 1, 1, 1, 1, 1, 1, 1, 5, 5)
+    ws = torch.empty(16, device=DEV)
+    rc = L.ddcn_deform_conv_forward_f32(_lib.ptr(x), _lib.ptr(w), None, _lib.ptr(x), _lib.ptr(x), _lib.ptr(ws), 64, g,
+                                        _lib.current_stream(torch.device(DEV)))
+    assert rc == -3 and b"workspace too small" in L.ddcn_last_error()
+    rc = L.ddcn_im2col_f32(None, _lib.ptr(x), None, _lib.ptr(x), g, None)
+    assert rc == -1
+
+
+def test_non_default_stream_and_no_grad_inputs():
+    c = cases.SMALL_CASES[3]
+    g = load_golden(c["name"])
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        out, grads = _run_hip(c, g)
+    _assert_case(c, out, grads, g)
+    # forward only, nothing requires grad: nothing saved, no backward
+    out2 = pkg.modulated_deform_conv(_t(g["x"]), _t(g["offset"]), _t(g["mask"]), _t(g["weight"]), _t(g["bias"]),
+                                     c["stride"], c["pad"], c["dil"], c["groups"], c["dg"])
+    assert not out2.requires_grad
+    assert cases.relerr(out2.cpu().numpy(), g["out"]) <= FWD_TOL
+
+
+# ---------------------------------------------------------------- full size (BASELINE config 1 layer)
+def _config1(n=2, seed=0, off_scale=2.0):
+    gen = torch.Generator(device="cpu").manual_seed(seed)
+    x = torch.randn(n, 512, 97, 97, generator=gen)
+    w = (torch.rand(512, 512, 3, 3, generator=gen) * 2 - 1) / (4608 ** 0.5)
+    off = torch.randn(n, 18, 97, 97, generator=gen) * off_scale
+    mask = torch.sigmoid(torch.randn(n, 9, 97, 97, generator=gen))
+    gout = torch.randn(n, 512, 97, 97, generator=gen)
+    return x, w, off, mask, gout
+
+
+def test_full_size_config1_against_oracle_one_image():
+    """One image of the res5 layer (C=512->512, 97x97, dil=pad=4) against the fp32 oracle run on the host
+    (the fp64 oracle takes the same few seconds; fp64 is used so the bar is the stated one)."""
+    x, w, off, mask, gout = _config1(n=1, seed=1)
+    xd, wd, od, md = (t.to(DEV).requires_grad_(True) for t in (x, w, off, mask))
+    out = pkg.modulated_deform_conv(xd, od, md, wd, None, 1, 4, 4, 1, 1)
+    out.backward(gout.to(DEV))
+    f64 = lambda t: t.numpy().astype(np.float64)
+    eout = orc.deform_forward(f64(x), f64(off), f64(mask), f64(w), None, 1, 4, 4, 1, 1)
+    egx, egoff, egmask, egw, _ = orc.deform_backward(f64(x), f64(off), f64(mask), f64(w), f64(gout), False, 1, 4, 4, 1, 1)
+    assert cases.relerr(out.detach().cpu().numpy(), eout) <= FWD_TOL
+    assert cases.relerr(xd.grad.cpu().numpy(), egx) <= BWD_TOL
+    assert cases.relerr(od.grad.cpu().numpy(), egoff) <= BWD_TOL
+    assert cases.relerr(md.grad.cpu().numpy(), egmask) <= BWD_TOL
+    assert cases.relerr(wd.grad.cpu().numpy(), egw) <= BWD_TOL
+
+
+def test_full_size_config1_properties():
+    """Size-independent properties at BASELINE config 1 (N=2): zero offsets + unit mask == dilated conv2d;
+    linearity in the weight; gradient of sum(out) w.r.t. bias-free weight equals the summed columns identity
+    <gW, W> == <out, gout> (Euler identity for a map linear in W)."""
+    x, w, off, mask, gout = _config1(n=2, seed=2)
+    xd, wd, od, md, gd = (t.to(DEV) for t in (x, w, off, mask, gout))
+    zero = torch.zeros_like(od)
+    one = torch.ones_like(md)
+    out0 = pkg.modulated_deform_conv(xd, zero, one, wd, None, 1, 4, 4, 1, 1)
+    ref = torch.nn.functional.conv2d(xd.double(), wd.double(), None, 1, 4, 4).float()
+    assert ((out0 - ref).abs().max() / ref.abs().max()).item() <= FWD_TOL
+    # linearity in W
+    w2 = torch.randn_like(wd) / 68.0
+    o1 = pkg.modulated_deform_conv(xd, od, md, wd, None, 1, 4, 4, 1, 1)
+    o2 = pkg.modulated_deform_conv(xd, od, md, w2, None, 1, 4, 4, 1, 1)
+    o12 = pkg.modulated_deform_conv(xd, od, md, wd + 0.5 * w2, None, 1, 4, 4, 1, 1)
+    assert ((o12 - (o1 + 0.5 * o2)).abs().max() / o12.abs().max()).item() <= 1e-5
+    # <gW, W> == <out, gout>  and  <gx, x> == <out, gout>  (the op is linear in W and in x)
+    wg = wd.clone().requires_grad_(True)
+    xg = xd.clone().requires_grad_(True)
+    o = pkg.modulated_deform_conv(xg, od, md, wg, None, 1, 4, 4, 1, 1)
+    o.backward(gd)
+    lhs = (o.detach().double() * gd.double()).sum()
+    assert abs(((wg.grad.double() * wd.double()).sum() - lhs) / lhs).item() <= 1e-4
+    assert abs(((xg.grad.double() * xd.double()).sum() - lhs) / lhs).item() <= 1e-4
