@@ -1,0 +1,232 @@
+#!/usr/bin/env python3
+"""bench.py -- DDCN operator forward+backward on MI355X (BASELINE.json metric "DDCN op fwd+bwd GB/s & %MFMA").
+
+A step = one forward + one backward of the modulated DDCN op (the main op of the reference's
+DepthDeformConvPack, detseg/ops/dcn/deform_conv.py:457-463) through the autograd.Function boundary, on
+synthetic inputs already resident in HBM.  Workload = BASELINE.json configs[0] layer: ResNet res5 shape,
+N=2 per GPU, C=512->512, 97x97, 3x3, stride 1, pad=dilation=4, groups=1, deformable_groups=1, fp32.
+(configs[1], the whole DDCN-ResNet50 model, needs the model callers -- SURVEY.md 8(f3), "next".)
+
+value = algorithmic gather/scatter bytes of the reference algorithm per step (SURVEY.md 8(d):
+775.8 MB/image = 2*B_im2col + B_col2im + B_coord) * images / time.  The op is MFMA-bound overall, so the
+JSON line also carries op TFLOP/s and a roofline entry per kernel (measured live with HIP events on the
+launch stream).  With --gpus N every rank runs the same per-GPU batch (weak scaling, images partitioned over
+ranks) and all-reduces grad_weight (SUM, then /world) as the reference's data-parallel training does
+(detseg/core/utils/dist_utils.py:22-28).
+"""
+import argparse
+import ctypes
+import importlib
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+MFMA_F32_PEAK_TF = 157.3   # MI355X_MICROARCH.md: FP32 matrix 157.3 TFLOP/s
+
+
+def workload(args):
+    return dict(N=args.batch, C=args.channels, Co=args.channels, H=args.size, W=args.size, k=3, stride=1,
+                pad=args.dilation, dil=args.dilation, groups=1, dg=1)
+
+
+def alg_numbers(w):
+    """SURVEY.md 8(d) algorithmic bytes / flops per image (fp32, modulated)."""
+    e, C, K2 = 4, w["C"], w["k"] * w["k"]
+    P = w["H"] * w["W"]  # stride 1, pad = dil -> Ho = H
+    HW = w["H"] * w["W"]
+    dg = w["dg"]
+    b_im2col = e * (C * HW + 3 * dg * K2 * P + C * K2 * P)
+    b_col2im = b_im2col
+    b_coord = e * (C * K2 * P + C * HW + 3 * dg * K2 * P + 3 * dg * K2 * P)
+    b_fused = e * (C * K2 * P + 2 * C * HW + 2 * 3 * dg * K2 * P)
+    f_gemm = 2.0 * w["Co"] * C * K2 * P
+    return dict(b_im2col=b_im2col, b_col2im=b_col2im, b_coord=b_coord, b_fused=b_fused, f_gemm=f_gemm,
+                b_total=2 * b_im2col + b_col2im + b_coord, f_total=3 * f_gemm)
+
+
+def make_inputs(w, dev, seed):
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    N, C, H, W = w["N"], w["C"], w["H"], w["W"]
+    K = C * 9
+    x = torch.randn(N, C, H, W, generator=g)
+    weight = (torch.rand(w["Co"], C, 3, 3, generator=g) * 2 - 1) / (K ** 0.5)
+    offset = torch.randn(N, 18, H, W, generator=g) * 2
+    mask = torch.sigmoid(torch.randn(N, 9, H, W, generator=g))
+    gout = torch.randn(N, w["Co"], H, W, generator=g)
+    return [t.to(dev) for t in (x, weight, offset, mask, gout)]
+
+
+def time_stage(fn, iters, warmup=2):
+    for _ in range(warmup):
+        fn()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    s.record()
+    for _ in range(iters):
+        fn()
+    e.record()
+    torch.cuda.synchronize()
+    return s.elapsed_time(e) / iters  # ms per launch
+
+
+def kernel_rooflines(w, tensors, iters):
+    """Average launch duration of every stage kernel (HIP events on the launch stream = torch's current)."""
+    _lib = importlib.import_module("semantic-segmentation_amd.dcn._lib")
+    L = _lib.lib()
+    x, weight, offset, mask, gout = tensors
+    N = w["N"]
+    g = _lib.Geom(N, w["C"], w["H"], w["W"], w["Co"], 3, 3, 1, 1, w["pad"], w["pad"], w["dil"], w["dil"], 1, 1,
+                  w["H"], w["W"])
+    col = torch.empty(L.ddcn_workspace_bytes(g) // 4, device=x.device)
+    out = torch.empty_like(gout)
+    gx, goff, gmask, gw = (torch.zeros_like(t) for t in (x, offset, mask, weight))
+    s = _lib.current_stream(x.device)
+    p = _lib.ptr
+    a = alg_numbers(w)
+    stages = [
+        ("im2col", "hbm", a["b_im2col"] * N,
+         lambda: _lib.check(L.ddcn_im2col_f32(p(x), p(offset), p(mask), p(col), g, s))),
+        ("gemm_out", "mfma", a["f_gemm"] * N,
+         lambda: _lib.check(L.ddcn_gemm_out_f32(p(weight), p(col), None, p(out), g, s))),
+        ("gemm_gcol", "mfma", a["f_gemm"] * N,
+         lambda: _lib.check(L.ddcn_gemm_gcol_f32(p(weight), p(gout), p(col), g, s))),
+        ("col2im_coord", "hbm", a["b_fused"] * N,
+         lambda: _lib.check(L.ddcn_col2im_coord_f32(p(col), p(x), p(offset), p(mask), p(gx), p(goff), p(gmask), g, s))),
+        ("gemm_gweight", "mfma", a["f_gemm"] * N,
+         lambda: _lib.check(L.ddcn_gemm_gweight_f32(p(gout), p(col), p(gw), g, s))),
+    ]
+    res = []
+    for name, bound, work, fn in stages:
+        ms = time_stage(fn, iters)
+        if bound == "hbm":
+            ach, peak, unit = work / ms / 1e6, HBM_PEAK_GBS, "GB/s"
+        else:
+            ach, peak, unit = work / ms / 1e9, MFMA_F32_PEAK_TF, "TFLOP/s"
+        res.append(dict(kernel=name, bound=bound, ms=round(ms, 4), achieved=round(ach, 2), peak=peak, unit=unit,
+                        frac=round(ach / peak, 4), traffic=None))
+    return res
+
+
+def cpu_baseline(w, threads):
+    """The CPU oracle (a port of the reference algorithm; the reference has no CPU path) on ONE image of the
+    same layer, fwd+bwd, fp32, timed on this host."""
+    from oracle import ddcn_oracle as orc
+    import numpy as np
+    orc.set_threads(threads)
+    rng = np.random.default_rng(0)
+    C, H, W = w["C"], w["H"], w["W"]
+    x = rng.standard_normal((1, C, H, W)).astype(np.float32)
+    weight = (rng.uniform(-1, 1, (w["Co"], C, 3, 3)) / np.sqrt(C * 9)).astype(np.float32)
+    offset = (rng.standard_normal((1, 18, H, W)) * 2).astype(np.float32)
+    mask = (1 / (1 + np.exp(-rng.standard_normal((1, 9, H, W))))).astype(np.float32)
+    gout = rng.standard_normal((1, w["Co"], H, W)).astype(np.float32)
+    kw = dict(stride=1, padding=w["pad"], dilation=w["dil"], groups=1, deformable_groups=1)
+    t0 = time.perf_counter()
+    orc.deform_forward(x, offset, mask, weight, None, **kw)
+    orc.deform_backward(x, offset, mask, weight, gout, False, **kw)
+    dt = time.perf_counter() - t0
+    a = alg_numbers(w)
+    return dict(value=round(a["b_total"] / dt / 1e9, 4), unit="GB/s", cores=threads, kind="port",
+                sample="1 image of the workload layer, fwd+bwd, fp32 C oracle (OpenMP), %.2f s" % dt,
+                tflops=round(a["f_total"] / dt / 1e12, 4))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=2, help="images per GPU")
+    ap.add_argument("--channels", type=int, default=512)
+    ap.add_argument("--size", type=int, default=97)
+    ap.add_argument("--dilation", type=int, default=4)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-timing", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)   # "nccl" is RCCL on ROCm
+    pkg = importlib.import_module("semantic-segmentation_amd")
+
+    w = workload(args)
+    x, weight, offset, mask, gout = make_inputs(w, dev, seed=1234 + rank)
+    x.requires_grad_(True); weight.requires_grad_(True); offset.requires_grad_(True); mask.requires_grad_(True)
+
+    def step():
+        for t in (x, weight, offset, mask):
+            t.grad = None
+        out = pkg.modulated_deform_conv(x, offset, mask, weight, None, 1, w["pad"], w["dil"], 1, 1)
+        out.backward(gout)
+        if world > 1:   # data-parallel gradient exchange of the layer's parameter (SUM then /world)
+            dist.all_reduce(weight.grad)
+            weight.grad.div_(world)
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+
+    a = alg_numbers(w)
+    images = w["N"] * world * args.steps
+    line = {
+        "metric": "DDCN op fwd+bwd GB/s",
+        "value": round(a["b_total"] * images / dt / 1e9, 2),
+        "unit": "GB/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(dt / args.steps * 1e3, 4),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "BASELINE configs[0] layer: modulated DDCN 3x3, N=%d/GPU, C=%d->%d, %dx%d, "
+                               "stride 1, pad=dil=%d, groups 1, dg 1, fwd+bwd" %
+                               (w["N"], w["C"], w["Co"], w["H"], w["W"], w["dil"]),
+                   "images_per_gpu": w["N"], "parallelism": "dp%d" % world,
+                   "alg_bytes_per_image": a["b_total"], "alg_flops_per_image": a["f_total"]},
+        "op_tflops": round(a["f_total"] * images / dt / 1e12, 2),
+        "images_per_s": round(images / dt, 2),
+    }
+    if rank == 0 and world == 1 and not args.no_kernel_timing:
+        ks = kernel_rooflines(w, [t.detach() for t in (x, weight, offset, mask)] + [gout], max(5, args.steps // 2))
+        dom = max((k for k in ks if k["bound"] == "mfma"), key=lambda k: k["ms"])
+        line["roofline"] = {k: dom[k] for k in ("bound", "achieved", "peak", "unit", "frac", "traffic")}
+        line["roofline"]["kernel"] = dom["kernel"]
+        line["roofline_kernels"] = ks
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        threads = min(16, os.cpu_count() or 1)
+        line["cpu_baseline"] = cpu_baseline(w, threads)
+    if rank == 0:
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
