@@ -66,11 +66,16 @@ def make_inputs(c):
     x = rng.standard_normal((N, Ci, H, W))
     weight = rng.uniform(-1, 1, (Co, Ci // c["groups"], c["kh"], c["kw"])) / np.sqrt(Ci * K2)
     bias = rng.standard_normal((Co,)) if c["bias"] else None
-    offset = rng.standard_normal((N, c["dg"] * 2 * K2, Ho, Wo)) * c["off_scale"]
+    # Offsets are quantised to odd multiples of 2^-11 (never an integer) so that (integer tap position + offset) is exact in fp32:
+    # d/d(offset) of bilinear sampling is discontinuous at integer coordinates, and an fp32 rounding of the sum
+    # across such a boundary would make an fp32 implementation and the fp64 oracle pick different cells.
+    offset = (np.floor(rng.standard_normal((N, c["dg"] * 2 * K2, Ho, Wo)) * c["off_scale"] * 1024.0) + 0.5) / 1024.0
     mask = 1.0 / (1.0 + np.exp(-rng.standard_normal((N, c["dg"] * K2, Ho, Wo)))) if c["modulated"] else None
     gout = rng.standard_normal((N, Co, Ho, Wo))
     depth = rng.standard_normal((N, 1, H, W))
     sp = c["special"]
+    if c["off_scale"] == 0.0:
+        offset[:] = 0.0
     if sp == "edges":
         # hand-placed coordinates: the sample position is base + offset; drive it to special values
         off = offset.reshape(N, c["dg"], K2, 2, Ho, Wo)
@@ -78,7 +83,7 @@ def make_inputs(c):
                  (np.arange(K2) // c["kw"] * c["dil"]).reshape(1, 1, K2, 1, 1)
         base_w = (np.arange(Wo) * c["stride"] - c["pad"]).reshape(1, 1, 1, 1, Wo) + \
                  (np.arange(K2) % c["kw"] * c["dil"]).reshape(1, 1, K2, 1, 1)
-        targets = np.array([-1.0, -0.5, -0.999, -1.5, -3.25, 0.0, 2.0, H - 1.0, H - 0.5, float(H), H + 2.5,
+        targets = np.array([-1.0, -0.5, -1023.0 / 1024.0, -1.5, -3.25, 0.0, 2.0, H - 1.0, H - 0.5, float(H), H + 2.5,
                             1.25, 0.75, -0.25])
         th = targets[rng.integers(0, len(targets), size=(N, c["dg"], K2, Ho, Wo))]
         tw = targets[rng.integers(0, len(targets), size=(N, c["dg"], K2, Ho, Wo))]

@@ -304,7 +304,8 @@ def _config1(n=2, seed=0, off_scale=2.0):
     gen = torch.Generator(device="cpu").manual_seed(seed)
     x = torch.randn(n, 512, 97, 97, generator=gen)
     w = (torch.rand(512, 512, 3, 3, generator=gen) * 2 - 1) / (4608 ** 0.5)
-    off = torch.randn(n, 18, 97, 97, generator=gen) * off_scale
+    # odd multiples of 2^-11: tap position + offset is exact in fp32 and never an integer (see cases.make_inputs)
+    off = (torch.floor(torch.randn(n, 18, 97, 97, generator=gen) * off_scale * 1024) + 0.5) / 1024
     mask = torch.sigmoid(torch.randn(n, 9, 97, 97, generator=gen))
     gout = torch.randn(n, 512, 97, 97, generator=gen)
     return x, w, off, mask, gout
