@@ -38,6 +38,8 @@ int launch_im2col(const float *x, const float *offset, const float *mask, float 
                   hipStream_t stream);
 int launch_col2im_coord(const float *gcol, const float *x, const float *offset, const float *mask, float *gx,
                         float *goff, float *gmask, const ddcn_geom &g, hipStream_t stream);
+int launch_col2im_coord_tiled(const float *gcol, const float *x, const float *offset, const float *mask, float *gx,
+                              float *goff, float *gmask, const ddcn_geom &g, hipStream_t stream, bool *handled);
 int launch_depthaware_im2col(const float *x, const float *depth, float *col, const ddcn_geom &g,
                              hipStream_t stream);
 int launch_depthaware_col2im(const float *gcol, const float *depth, float *gx, const ddcn_geom &g,
