@@ -15,6 +15,8 @@
 //               ("escapees") fall back to global atomics.  After each chunk the footprint is flushed with
 //               one global atomic per touched cell -- neighbouring tiles overlap by the halo, so the flush
 //               still has to be atomic, but it issues ~7x fewer global atomics than a direct scatter.
+#include <stdlib.h>
+
 #include "ddcn_common.h"
 
 namespace ddcn {
@@ -31,13 +33,20 @@ struct TileArgs {
     int CG, CC, M;
     int RH, RW, RS;
     int stepR, stepC;  // TT / RW, TT % RW
+    int ablate;
 };
 
-template <int K2, bool MOD>
+template <bool MOD>
 __global__ __launch_bounds__(TT) void col2im_coord_tile_kernel(TileArgs a)
 {
-    extern __shared__ __attribute__((aligned(16))) float gs[];
+    extern __shared__ __attribute__((aligned(16))) float smem[];
     const ddcn_geom &g = a.g;
+    const int K2 = g.kh * g.kw;
+    float *acc = smem;                       // [3*K2][TT]: d/d(off_h), d/d(off_w), d/d(mask) per tap, thread-private columns
+    // [CC][RS] grad_input footprint of the tile, in DOUBLE: measured on gfx950 (tools/ubench_lds_atomic.hip),
+    // ds_add_f32 retires ~1 lane per 3 clocks (195 cycles per wave-instruction) while ds_add_f64 runs at
+    // ~10 cycles per wave-instruction -- the f64 atomic is 8-20x faster and also sums more accurately
+    double *gs = reinterpret_cast<double *>(smem + 3 * K2 * TT);
     const int t = threadIdx.x;
     const int tyi = blockIdx.x / a.tiles_w, txi = blockIdx.x - tyi * a.tiles_w;
     const int ty = t / a.TW, tx = t - ty * a.TW;
@@ -50,34 +59,11 @@ __global__ __launch_bounds__(TT) void col2im_coord_tile_kernel(TileArgs a)
     const int rw0 = txi * a.TW * g.sw - g.pw - a.M;
     const int HW = g.H * g.W;
     const int p = live ? ho * g.Wo + wo : 0;
+    const int h_in = ho * g.sh - g.ph, w_in = wo * g.sw - g.pw;
+    const float *off = a.offset + ((long)n * g.dg + dgi) * 2 * K2 * a.P + p;
+    const float *msk = MOD ? a.mask + ((long)n * g.dg + dgi) * K2 * a.P + p : nullptr;
 
-    // ---- per-tap sample state, kept for the whole channel group
-    int hw[K2];          // ((hl + 1) << 16) | (wl + 1), or -1 when the sample is outside (-1,H)x(-1,W)
-    float sh_[K2], sw_[K2], sm_[K2];
-    float acc_h[K2], acc_w[K2], acc_m[K2];
-    {
-        const float *off = a.offset + ((long)n * g.dg + dgi) * 2 * K2 * a.P + p;
-        const float *msk = MOD ? a.mask + ((long)n * g.dg + dgi) * K2 * a.P + p : nullptr;
-        const int h_in = ho * g.sh - g.ph, w_in = wo * g.sw - g.pw;
-#pragma unroll
-        for (int k = 0; k < K2; ++k) {
-            acc_h[k] = acc_w[k] = acc_m[k] = 0.f;
-            hw[k] = -1; sh_[k] = sw_[k] = 0.f; sm_[k] = 1.f;
-            if (live) {
-                const int i = k / g.kw, j = k - i * g.kw;
-                const float h = (float)(h_in + i * g.dh) + off[(long)(2 * k) * a.P];
-                const float w = (float)(w_in + j * g.dw) + off[(long)(2 * k + 1) * a.P];
-                if (MOD) sm_[k] = msk[(long)k * a.P];
-                if (h > -1.f && w > -1.f && h < (float)g.H && w < (float)g.W) {
-                    const int hl = (int)floorf(h), wl = (int)floorf(w);
-                    hw[k] = ((hl + 1) << 16) | (wl + 1);
-                    sh_[k] = h; sw_[k] = w;
-                }
-            }
-        }
-    }
-
-    for (int i = t; i < a.CC * a.RS; i += TT) gs[i] = 0.f;
+    for (int i = t; i < 3 * K2 * TT + 2 * a.CC * a.RS; i += TT) smem[i] = 0.f;
     const int fr0 = t / a.RW, fc0 = t - fr0 * a.RW;   // this thread's first footprint cell in the flush sweep
     __syncthreads();
 
@@ -85,16 +71,17 @@ __global__ __launch_bounds__(TT) void col2im_coord_tile_kernel(TileArgs a)
         const float *xb = a.x + ((long)n * g.C + c0) * HW;
         float *gxb = a.gx + ((long)n * g.C + c0) * HW;
         const float *gcb = a.gcol + ((long)n * g.C + c0) * K2 * a.ld + p;
-#pragma unroll
-        for (int k = 0; k < K2; ++k) {
-            if (hw[k] >= 0) {
-                const int hl = (hw[k] >> 16) - 1, wl = (hw[k] & 0xffff) - 1;
-                float h = sh_[k], w = sw_[k];
-                const float m = sm_[k];
-                int kk = k;
-                // keep the per-tap weights from being hoisted out of the channel-group loop (9 taps x ~20
-                // loop-invariant registers would spill): make their inputs opaque once per chunk
-                asm volatile("" : "+v"(h), "+v"(w), "+s"(kk));
+        if (live) {
+            int ki = 0, kj = 0;
+            for (int k = 0; k < K2; ++k) {
+                // sample position of (pixel, tap): recomputed per chunk (3 cached loads + ~30 VALU against
+                // CC * ~35 instructions of channel work) instead of holding 9 taps of state in registers
+                const float h = (float)(h_in + ki * g.dh) + off[(long)(2 * k) * a.P];
+                const float w = (float)(w_in + kj * g.dw) + off[(long)(2 * k + 1) * a.P];
+                const float m = MOD ? msk[(long)k * a.P] : 1.f;
+                if (++kj == g.kw) { kj = 0; ++ki; }
+                if (!(h > -1.f && w > -1.f && h < (float)g.H && w < (float)g.W)) continue;
+                const int hl = (int)floorf(h), wl = (int)floorf(w);
                 const bool ok1 = hl >= 0 && wl >= 0, ok2 = hl >= 0 && wl + 1 <= g.W - 1;
                 const bool ok3 = hl + 1 <= g.H - 1 && wl >= 0, ok4 = hl + 1 <= g.H - 1 && wl + 1 <= g.W - 1;
                 const int gi = hl * g.W + wl;                       // plane index of the (hl, wl) corner
@@ -111,14 +98,17 @@ __global__ __launch_bounds__(TT) void col2im_coord_tile_kernel(TileArgs a)
                 const float cwl = fwl + 1.f - w, cwh = w - fwl;
                 const float chl = fhl + 1.f - h, chh = h - fhl;
                 float ah = 0.f, aw = 0.f, am = 0.f;
-#pragma unroll 2
+                const float *gck = gcb + (long)k * a.ld;
+#pragma unroll 4
                 for (int cc = 0; cc < a.CC; ++cc) {
                     const float *im = xb + cc * HW + gi;
-                    const float gc = gcb[((long)cc * K2 + kk) * a.ld];
-                    const float v1 = ok1 ? im[0] : 0.f;
-                    const float v2 = ok2 ? im[1] : 0.f;
-                    const float v3 = ok3 ? im[g.W] : 0.f;
-                    const float v4 = ok4 ? im[g.W + 1] : 0.f;
+                    const float gc = (a.ablate & 8) ? h : gck[(long)cc * K2 * a.ld];
+                    float v1, v2, v3, v4;
+                    if (a.ablate & 4) { v1 = v2 = v3 = v4 = gc; } else {
+                    v1 = ok1 ? im[0] : 0.f;
+                    v2 = ok2 ? im[1] : 0.f;
+                    v3 = ok3 ? im[g.W] : 0.f;
+                    v4 = ok4 ? im[g.W + 1] : 0.f; }
                     float wh = 0.f, ww = 0.f;
                     wh += -1.f * cwl * v1; wh += -1.f * cwh * v2; wh += cwl * v3; wh += cwh * v4;
                     ww += -1.f * chl * v1; ww += chl * v2; ww += -1.f * chh * v3; ww += chh * v4;
@@ -133,12 +123,13 @@ __global__ __launch_bounds__(TT) void col2im_coord_tile_kernel(TileArgs a)
                         aw += ww * gc;
                         tg = gc;
                     }
+                    if (a.ablate & 1) { am += tg * s1 + s2 + s3 + s4; } else
                     if (inreg) {
-                        float *cell = gs + cc * a.RS + ri;
-                        if (ok1) atomicAdd(cell, s1 * tg);
-                        if (ok2) atomicAdd(cell + 1, s2 * tg);
-                        if (ok3) atomicAdd(cell + a.RW, s3 * tg);
-                        if (ok4) atomicAdd(cell + a.RW + 1, s4 * tg);
+                        double *cell = gs + cc * a.RS + ri;
+                        if (ok1) atomicAdd(cell, (double)(s1 * tg));
+                        if (ok2) atomicAdd(cell + 1, (double)(s2 * tg));
+                        if (ok3) atomicAdd(cell + a.RW, (double)(s3 * tg));
+                        if (ok4) atomicAdd(cell + a.RW + 1, (double)(s4 * tg));
                     } else {
                         float *cell = gxb + cc * HW + gi;
                         if (ok1) atomicAdd(cell, s1 * tg);
@@ -147,21 +138,25 @@ __global__ __launch_bounds__(TT) void col2im_coord_tile_kernel(TileArgs a)
                         if (ok4) atomicAdd(cell + g.W + 1, s4 * tg);
                     }
                 }
-                acc_h[k] += ah; acc_w[k] += aw; acc_m[k] += am;
+                float *ak = acc + (3 * k) * TT + t;   // thread-private: plain read-modify-write
+                ak[0] += ah;
+                ak[TT] += aw;
+                if (MOD) ak[2 * TT] += am;
             }
         }
         __syncthreads();
         // flush the footprint: one global atomic per touched in-image cell, and re-zero for the next chunk
+        if (!(a.ablate & 2))
         for (int cc = 0; cc < a.CC; ++cc) {
-            float *gsc = gs + cc * a.RS;
+            double *gsc = gs + cc * a.RS;
             float *gxc = gxb + cc * HW;
             int r = fr0, c = fc0;
             for (int i = t; i < a.RS; i += TT) {
-                const float v = gsc[i];
-                if (v != 0.f) {
-                    gsc[i] = 0.f;
+                const double v = gsc[i];
+                if (v != 0.0) {
+                    gsc[i] = 0.0;
                     const int y = rh0 + r, xx = rw0 + c;
-                    if (y >= 0 && y < g.H && xx >= 0 && xx < g.W) atomicAdd(gxc + y * g.W + xx, v);
+                    if (y >= 0 && y < g.H && xx >= 0 && xx < g.W) atomicAdd(gxc + y * g.W + xx, (float)v);
                 }
                 r += a.stepR; c += a.stepC;
                 if (c >= a.RW) { c -= a.RW; r += 1; }
@@ -173,13 +168,15 @@ __global__ __launch_bounds__(TT) void col2im_coord_tile_kernel(TileArgs a)
     if (live) {
         float *goffb = a.goff + ((long)n * g.dg + dgi) * 2 * K2 * a.P + p;
         float *gmaskb = MOD ? a.gmask + ((long)n * g.dg + dgi) * K2 * a.P + p : nullptr;
-#pragma unroll
         for (int k = 0; k < K2; ++k) {
-            // invalid samples contribute exactly 0 (K:422-425, K:746-749); destination was cleared by the launcher
-            if (hw[k] >= 0) {
-                atomicAdd(goffb + (long)(2 * k) * a.P, acc_h[k]);
-                atomicAdd(goffb + (long)(2 * k + 1) * a.P, acc_w[k]);
-                if (MOD) atomicAdd(gmaskb + (long)k * a.P, acc_m[k]);
+            // taps whose sample is invalid accumulated nothing: adding 0 keeps the cleared destination
+            const float *ak = acc + (3 * k) * TT + t;
+            const float vh = ak[0], vw = ak[TT];
+            if (vh != 0.f) atomicAdd(goffb + (long)(2 * k) * a.P, vh);
+            if (vw != 0.f) atomicAdd(goffb + (long)(2 * k + 1) * a.P, vw);
+            if (MOD) {
+                const float vm = ak[2 * TT];
+                if (vm != 0.f) atomicAdd(gmaskb + (long)k * a.P, vm);
             }
         }
     }
@@ -189,7 +186,7 @@ __global__ __launch_bounds__(TT) void col2im_coord_tile_kernel(TileArgs a)
 static bool plan_tiles(const ddcn_geom &g, TileArgs &a)
 {
     const Dims d = dims_of(g);
-    if (d.K2 != 9 || g.kh != 3) return false;
+    if (d.K2 > 9) return false;   // accumulators: 3*K2 KiB of LDS
     if (g.H >= 32766 || g.W >= 32766) return false;
     // tile width: least padding waste among 16..32 (or the whole row when narrower)
     int TW;
@@ -212,13 +209,16 @@ static bool plan_tiles(const ddcn_geom &g, TileArgs &a)
     int CG = d.cpg;
     while (CG % 2 == 0 && (long)tiles * g.N * (g.C / CG) < 1024 && CG > 8) CG /= 2;
     a.CG = CG;
-    const size_t lds_cap = 48 * 1024;
-    for (int M = 6; M >= 0; M -= 2) {
+    const size_t acc_bytes = (size_t)3 * d.K2 * TT * sizeof(float);
+    static const int env_kb = getenv("DDCN_TILE_LDS_KB") ? atoi(getenv("DDCN_TILE_LDS_KB")) : 0;   // tuning knob
+    static const int env_m = getenv("DDCN_TILE_MARGIN") ? atoi(getenv("DDCN_TILE_MARGIN")) : 6;
+    const size_t lds_cap = (size_t)(env_kb > 0 ? env_kb : 76) * 1024;   // default: two workgroups per CU
+    for (int M = env_m; M >= 0; M -= 2) {
         const int RH = (TH - 1) * g.sh + (g.kh - 1) * g.dh + 2 + 2 * M;
         const int RW = (TW - 1) * g.sw + (g.kw - 1) * g.dw + 2 + 2 * M;
         for (int CC = 8; CC >= 1; CC /= 2) {
             if (CG % CC) continue;
-            if ((size_t)CC * RH * RW * sizeof(float) <= lds_cap && (CC >= 4 || M == 0 || CG < 4)) {
+            if (acc_bytes + (size_t)CC * RH * RW * sizeof(double) <= lds_cap && (CC >= 4 || M == 0 || CG < 4)) {
                 a.M = M; a.RH = RH; a.RW = RW; a.RS = RH * RW; a.CC = CC;
                 a.stepR = TT / RW; a.stepC = TT % RW;
                 return true;
@@ -237,14 +237,19 @@ int launch_col2im_coord_tiled(const float *gcol, const float *x, const float *of
     *handled = true;
     const Dims d = dims_of(g);
     a.gcol = gcol; a.x = x; a.offset = offset; a.mask = mask; a.gx = gx; a.goff = goff; a.gmask = gmask;
+    a.ablate = getenv("DDCN_ABLATE") ? atoi(getenv("DDCN_ABLATE")) : 0;
     a.g = g; a.P = d.P; a.cpg = d.cpg; a.ld = d.ld;
     dim3 grid(a.tiles_w * ((g.Ho + a.TH - 1) / a.TH), g.C / a.CG, g.N);
     if (grid.y > 65535 || grid.z > 65535) return fail(DDCN_ERR_UNSUPPORTED, "col2im_coord_tile: grid too large");
-    const size_t smem = (size_t)a.CC * a.RS * sizeof(float);
+    const size_t smem = (size_t)(3 * d.K2 * TT + 2 * a.CC * a.RS) * sizeof(float);
+    const void *fn = mask ? reinterpret_cast<const void *>(&col2im_coord_tile_kernel<true>)
+                          : reinterpret_cast<const void *>(&col2im_coord_tile_kernel<false>);
+    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    if (e != hipSuccess) return fail(DDCN_ERR_LAUNCH, "col2im_coord_tile: hipFuncSetAttribute: %s", hipGetErrorString(e));
     if (mask)
-        hipLaunchKernelGGL((col2im_coord_tile_kernel<9, true>), grid, dim3(TT), smem, stream, a);
+        hipLaunchKernelGGL((col2im_coord_tile_kernel<true>), grid, dim3(TT), smem, stream, a);
     else
-        hipLaunchKernelGGL((col2im_coord_tile_kernel<9, false>), grid, dim3(TT), smem, stream, a);
+        hipLaunchKernelGGL((col2im_coord_tile_kernel<false>), grid, dim3(TT), smem, stream, a);
     return check_launch("col2im_coord_tile");
 }
 
