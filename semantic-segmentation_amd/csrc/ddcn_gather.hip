@@ -284,6 +284,10 @@ static GatherArgs base_args(const ddcn_geom &g)
 int launch_im2col(const float *x, const float *offset, const float *mask, float *col, const ddcn_geom &g,
                   hipStream_t stream)
 {
+    bool handled = false;
+    const int rc = launch_im2col_tiled(x, offset, mask, col, g, stream, &handled);
+    if (handled || rc != DDCN_OK) return rc;
+    // generic path (input patch of one tile too large for LDS)
     GatherArgs a = base_args(g);
     a.x = x; a.offset = offset; a.mask = mask; a.col = col;
     a.CH = pick_chunk(a.cpg, 16, 1);
