@@ -27,7 +27,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int IT = 256;
 constexpr int CC = 4;          // channels per LDS chunk (one ds_read_b128 per corner)
-constexpr int MAXCELLS = 8;    // staging registers: patch cells per thread (patch <= 8 * 256 cells), template NCELL
+constexpr int MAXCELLS = 12;    // staging registers: patch cells per thread (patch <= 8 * 256 cells), template NCELL
 constexpr unsigned OOBV = 0x80000000u;
 
 struct Im2colTileArgs {
@@ -39,6 +39,8 @@ struct Im2colTileArgs {
     int TH, TW, tiles_w, tiles, groups;   // groups = C / CG
     int CG, M;
     int RH, RW, RS;
+    int dbuf;       // 1: two LDS patch buffers (one barrier per chunk), 0: one buffer (two barriers, half the LDS)
+    int strip;      // 1: tile = 256 consecutive pixels (full-width patch rows), 0: TH x TW tile
 };
 
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t mk_rsrc(const void *base, long bytes)
@@ -48,7 +50,7 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t mk_rsrc(const void *base, long
 }
 
 template <bool MOD, int NCELL>
-__global__ __launch_bounds__(IT, 3) void im2col_tile_kernel(Im2colTileArgs a)
+__global__ __launch_bounds__(IT, 2) void im2col_tile_kernel(Im2colTileArgs a)
 {
     constexpr int K2 = 9;
     extern __shared__ __attribute__((aligned(16))) float smem[];   // 2 buffers of [RS][CC]
@@ -63,15 +65,27 @@ __global__ __launch_bounds__(IT, 3) void im2col_tile_kernel(Im2colTileArgs a)
     const int logical = (xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q) + (bid >> 3);
     const int grp = logical / a.tiles, tile = logical - grp * a.tiles;
 
-    const int tyi = tile / a.tiles_w, txi = tile - tyi * a.tiles_w;
-    const int ty = t / a.TW, tx = t - ty * a.TW;
-    const int ho = tyi * a.TH + ty, wo = txi * a.TW + tx;
-    const bool live = ty < a.TH && ho < g.Ho && wo < g.Wo;
+    int ho, wo, rh0, rw0;   // this thread's pixel; image row / column of patch cell (0, 0)
+    bool live;
+    if (a.strip) {
+        // 256 consecutive pixels: every column-row store of a wave is one contiguous 256-B run (measured
+        // 4.1 TB/s for this store shape against 2.2 TB/s for 25-pixel tile rows, tools/ubench_store_pattern.hip)
+        const int pix = tile * IT + t;
+        live = pix < a.P;
+        ho = pix / g.Wo; wo = pix - ho * g.Wo;
+        rh0 = (tile * IT / g.Wo) * g.sh - g.ph - a.M;
+        rw0 = -1;                                      // patch spans columns -1 .. W (all a valid sample can touch)
+    } else {
+        const int tyi = tile / a.tiles_w, txi = tile - tyi * a.tiles_w;
+        const int ty = t / a.TW, tx = t - ty * a.TW;
+        ho = tyi * a.TH + ty; wo = txi * a.TW + tx;
+        live = ty < a.TH && ho < g.Ho && wo < g.Wo;
+        rh0 = tyi * a.TH * g.sh - g.ph - a.M;
+        rw0 = txi * a.TW * g.sw - g.pw - a.M;
+    }
     const int n = blockIdx.z;
     const int cg0 = grp * a.CG;
     const int dgi = cg0 / a.cpg;
-    const int rh0 = tyi * a.TH * g.sh - g.ph - a.M;   // image row / column of patch cell (0, 0)
-    const int rw0 = txi * a.TW * g.sw - g.pw - a.M;
     const int HW = g.H * g.W;
     const int p = live ? ho * g.Wo + wo : 0;
 
@@ -150,8 +164,8 @@ __global__ __launch_bounds__(IT, 3) void im2col_tile_kernel(Im2colTileArgs a)
     const int nchunks = a.CG / CC;
     for (int ch = 0; ch < nchunks; ++ch) {
         const int c0 = cg0 + ch * CC;
-        const f32x4 *cur = (ch & 1) ? buf1 : buf0;
-        f32x4 *nxt = (ch & 1) ? buf0 : buf1;
+        const f32x4 *cur = (a.dbuf && (ch & 1)) ? buf1 : buf0;
+        f32x4 *nxt = (a.dbuf && !(ch & 1)) ? buf1 : buf0;
         if (ch + 1 < nchunks) stage_load(c0 + CC);
         __builtin_amdgcn_sched_barrier(0);
         if (live) {
@@ -160,45 +174,50 @@ __global__ __launch_bounds__(IT, 3) void im2col_tile_kernel(Im2colTileArgs a)
                 const float w1 = bw1[k], w2 = bw2[k], w3 = bw3[k], w4 = bw4[k];
                 const unsigned rowk = (unsigned)((c0 * K2 + k) * a.ld * 4);   // byte offset of column row (c0, k)
                 const unsigned rstep = (unsigned)(K2 * a.ld * 4);
-                float v[CC];
                 if (cell[k] != -1) {
-                    // in-patch (or invalid: weights irrelevant, result forced to 0 below)
+                    // in-patch (or invalid: weights irrelevant, result forced to 0 below); escapees: after the loop
                     const int ci = cell[k] < 0 ? 0 : cell[k];
                     const f32x4 a1 = cur[ci], a2 = cur[ci + 1], a3 = cur[ci + a.RW], a4 = cur[ci + a.RW + 1];
 #pragma unroll
                     for (int cc = 0; cc < CC; ++cc) {
                         float val = (w1 * a1[cc] + w2 * a2[cc] + w3 * a3[cc] + w4 * a4[cc]);
                         if (MOD) val = val * fm[k];
-                        v[cc] = cell[k] < 0 ? 0.f : val;
-                    }
-                } else {
-                    int hwk = ghw[k];
-                    asm volatile("" : "+v"(hwk));   // keep the rare path's flags/addresses out of registers across chunks
-                    const int hl = hwk >> 16, wl = (int)(short)(hwk & 0xffff);
-                    const bool ok1 = hl >= 0 && wl >= 0, ok2 = hl >= 0 && wl + 1 <= g.W - 1;
-                    const bool ok3 = hl + 1 <= g.H - 1 && wl >= 0, ok4 = hl + 1 <= g.H - 1 && wl + 1 <= g.W - 1;
-                    const float *im = a.x + ((long)n * g.C + c0) * HW + hl * g.W + wl;
-#pragma unroll
-                    for (int cc = 0; cc < CC; ++cc) {
-                        const float v1 = ok1 ? im[0] : 0.f;
-                        const float v2 = ok2 ? im[1] : 0.f;
-                        const float v3 = ok3 ? im[g.W] : 0.f;
-                        const float v4 = ok4 ? im[g.W + 1] : 0.f;
-                        float val = (w1 * v1 + w2 * v2 + w3 * v3 + w4 * v4);
-                        if (MOD) val = val * fm[k];
-                        v[cc] = val;
-                        im += HW;
+                        val = cell[k] < 0 ? 0.f : val;
+                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, val), rcol, pvo,
+                                                              rowk + cc * rstep, 0);
                     }
                 }
-#pragma unroll
-                for (int cc = 0; cc < CC; ++cc)
-                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v[cc]), rcol, pvo,
-                                                          rowk + cc * rstep, 0);
             }
         }
         __builtin_amdgcn_sched_barrier(0);
+        if (!a.dbuf) __syncthreads();   // every wave is done reading the single buffer
         if (ch + 1 < nchunks) stage_store(nxt);
         __syncthreads();
+    }
+    // ---- escapees: samples whose corners leave the staged patch, gathered from global memory once per
+    //      workgroup for the whole channel group (rare: |offset| beyond the margin)
+    if (live) {
+#pragma unroll
+        for (int k = 0; k < K2; ++k) {
+            if (cell[k] == -1) {
+                const int hl = ghw[k] >> 16, wl = (int)(short)(ghw[k] & 0xffff);
+                const bool ok1 = hl >= 0 && wl >= 0, ok2 = hl >= 0 && wl + 1 <= g.W - 1;
+                const bool ok3 = hl + 1 <= g.H - 1 && wl >= 0, ok4 = hl + 1 <= g.H - 1 && wl + 1 <= g.W - 1;
+                const float *im = a.x + ((long)n * g.C + cg0) * HW + hl * g.W + wl;
+                const float w1 = bw1[k], w2 = bw2[k], w3 = bw3[k], w4 = bw4[k];
+                for (int c = 0; c < a.CG; ++c) {
+                    const float v1 = ok1 ? im[0] : 0.f;
+                    const float v2 = ok2 ? im[1] : 0.f;
+                    const float v3 = ok3 ? im[g.W] : 0.f;
+                    const float v4 = ok4 ? im[g.W + 1] : 0.f;
+                    float val = (w1 * v1 + w2 * v2 + w3 * v3 + w4 * v4);
+                    if (MOD) val = val * fm[k];
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, val), rcol, pvo,
+                                                          (unsigned)(((cg0 + c) * K2 + k) * a.ld * 4), 0);
+                    im += HW;
+                }
+            }
+        }
     }
 }
 
@@ -231,7 +250,19 @@ int launch_im2col_tiled(const float *x, const float *offset, const float *mask, 
     a.tiles = a.tiles_w * ((g.Ho + TH - 1) / TH);
     static const int env_m = getenv("DDCN_TILE_MARGIN") ? atoi(getenv("DDCN_TILE_MARGIN")) : 6;   // tuning knobs
     static const int env_cg = getenv("DDCN_IM2COL_CG") ? atoi(getenv("DDCN_IM2COL_CG")) : 0;
+    static const int env_strip = getenv("DDCN_IM2COL_STRIP") ? atoi(getenv("DDCN_IM2COL_STRIP")) : 1;
     bool ok = false;
+    // strip mode (contiguous column stores) when the full-width patch fits the staging budget
+    for (int M = env_m; env_strip && M >= 2 && !ok; M -= 2) {
+        const int rows_span = (IT + g.Wo - 2) / g.Wo + 1;
+        const int RH = (rows_span - 1) * g.sh + (g.kh - 1) * g.dh + 2 + 2 * M;
+        const int RW = g.W + 2;
+        if (RH * RW <= MAXCELLS * IT) {
+            a.strip = 1; a.M = M; a.RH = RH; a.RW = RW; a.RS = RH * RW;
+            a.TW = g.Wo; a.TH = 1; a.tiles_w = 1; a.tiles = (d.P + IT - 1) / IT;
+            ok = true;
+        }
+    }
     for (int M = env_m; M >= 0 && !ok; M -= 2) {
         const int RH = (TH - 1) * g.sh + (g.kh - 1) * g.dh + 2 + 2 * M;
         const int RW = (TW - 1) * g.sw + (g.kw - 1) * g.dw + 2 + 2 * M;
@@ -253,7 +284,9 @@ int launch_im2col_tiled(const float *x, const float *offset, const float *mask, 
     const long nwg = (long)a.tiles * a.groups;
     if (nwg > 0x7fffffffL || g.N > 65535) return fail(DDCN_ERR_UNSUPPORTED, "im2col_tile: grid too large");
     dim3 grid((unsigned)nwg, 1, g.N);
-    const size_t smem = (size_t)2 * a.RS * CC * sizeof(float);
+    static const int env_dbuf = getenv("DDCN_IM2COL_DBUF") ? atoi(getenv("DDCN_IM2COL_DBUF")) : 0;
+    a.dbuf = env_dbuf;
+    const size_t smem = (size_t)(a.dbuf ? 2 : 1) * a.RS * CC * sizeof(float);
     const int ncell = (a.RS + IT - 1) / IT;
 #define DDCN_IM2COL_LAUNCH(NC)                                                                         \
     do {                                                                                               \
@@ -262,10 +295,23 @@ int launch_im2col_tiled(const float *x, const float *offset, const float *mask, 
         else                                                                                           \
             hipLaunchKernelGGL((im2col_tile_kernel<false, NC>), grid, dim3(IT), smem, stream, a);      \
     } while (0)
+    hipError_t e = hipSuccess;
+    if (smem > 64 * 1024) {
+        // > 64 KiB of dynamic LDS needs the opt-in (set for every instantiation that can be launched below)
+        const void *fns[] = {(const void *)&im2col_tile_kernel<true, 10>, (const void *)&im2col_tile_kernel<false, 10>,
+                             (const void *)&im2col_tile_kernel<true, 12>, (const void *)&im2col_tile_kernel<false, 12>,
+                             (const void *)&im2col_tile_kernel<true, 8>, (const void *)&im2col_tile_kernel<false, 8>,
+                             (const void *)&im2col_tile_kernel<true, 6>, (const void *)&im2col_tile_kernel<false, 6>};
+        for (const void *fn : fns)
+            if (e == hipSuccess) e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        if (e != hipSuccess) return fail(DDCN_ERR_LAUNCH, "im2col_tile: hipFuncSetAttribute: %s", hipGetErrorString(e));
+    }
     if (ncell <= 2) DDCN_IM2COL_LAUNCH(2);
     else if (ncell <= 4) DDCN_IM2COL_LAUNCH(4);
     else if (ncell <= 6) DDCN_IM2COL_LAUNCH(6);
-    else DDCN_IM2COL_LAUNCH(8);
+    else if (ncell <= 8) DDCN_IM2COL_LAUNCH(8);
+    else if (ncell <= 10) DDCN_IM2COL_LAUNCH(10);
+    else DDCN_IM2COL_LAUNCH(12);
 #undef DDCN_IM2COL_LAUNCH
     return check_launch("im2col_tile");
 }
