@@ -40,6 +40,8 @@ int launch_im2col_tiled(const float *x, const float *offset, const float *mask, 
                         hipStream_t stream, bool *handled);
 int launch_col2im_coord(const float *gcol, const float *x, const float *offset, const float *mask, float *gx,
                         float *goff, float *gmask, const ddcn_geom &g, hipStream_t stream);
+int launch_col2im_coord_tile9(const float *gcol, const float *x, const float *offset, const float *mask, float *gx,
+                              float *goff, float *gmask, const ddcn_geom &g, hipStream_t stream, bool *handled);
 int launch_col2im_coord_tiled(const float *gcol, const float *x, const float *offset, const float *mask, float *gx,
                               float *goff, float *gmask, const ddcn_geom &g, hipStream_t stream, bool *handled);
 int launch_depthaware_im2col(const float *x, const float *depth, float *col, const ddcn_geom &g,

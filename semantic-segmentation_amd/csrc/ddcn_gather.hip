@@ -307,7 +307,9 @@ int launch_col2im_coord(const float *gcol, const float *x, const float *offset, 
     if (e == hipSuccess && gmask) e = hipMemsetAsync(gmask, 0, sizeof(float) * (size_t)g.N * g.dg * a.K2 * a.P, stream);
     if (e != hipSuccess) return fail(DDCN_ERR_LAUNCH, "col2im_coord: memset: %s", hipGetErrorString(e));
     bool handled = false;
-    const int rc = launch_col2im_coord_tiled(gcol, x, offset, mask, gx, goff, gmask, g, stream, &handled);
+    int rc = launch_col2im_coord_tile9(gcol, x, offset, mask, gx, goff, gmask, g, stream, &handled);
+    if (handled || rc != DDCN_OK) return rc;
+    rc = launch_col2im_coord_tiled(gcol, x, offset, mask, gx, goff, gmask, g, stream, &handled);
     if (handled || rc != DDCN_OK) return rc;
     // generic path (any kernel size / footprint too large for LDS)
     a.CH = pick_chunk(a.cpg, 32, 1);

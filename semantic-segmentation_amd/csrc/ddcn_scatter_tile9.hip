@@ -1,0 +1,335 @@
+// Tiled backward scatter for 3x3 kernels: fused col2im + col2im_coord, everything staged in LDS (gfx950).
+//
+// Arithmetic: detseg/ops/dcn/src/deform_conv_cuda_kernel.cu K:278-334 / K:634-692 (col2im) and K:372-435 /
+// K:694-766 (col2im_coord), helpers K:116-187.  Formula-by-formula citations are in ddcn_gather.hip.
+//
+// workgroup = (TH x TW tile of output pixels, group of CG input channels, image n); thread = output pixel.
+//   registers : per tap the patch cell, the fractional parts and the mask of the pixel's sample, and four
+//               running sums S_i = sum_c gcol[c,k,p] * x[c, corner_i].  grad_offset and grad_mask are linear
+//               in the S_i (K:163-184, K:752), so they are formed once at the end, not per channel.
+//   LDS       : xs[cell][4]  (float)  input patch of the tile for 4 channels, zero outside the image;
+//               gs[cell][4]  (double) grad_input footprint for the same 4 channels.
+//               ds_add_f64 because ds_add_f32 is ~20x slower on gfx950 (tools/ubench_lds_atomic.hip).
+//   per chunk : 36 column loads (scalar row offsets) + the next patch in flight, then per tap
+//               4 ds_read_b128 + 16 FMA + 16 ds_add_f64, no branch per corner: corners outside the image are
+//               patch cells that hold x = 0 and whose gradient is simply never flushed (== the reference's
+//               guards K:97-108, K:322-325).  Then the touched cells are flushed with one global atomic each.
+//   escapees  : samples whose corners leave the patch are handled after the channel loop, from global memory.
+#include <stdlib.h>
+
+#include "ddcn_common.h"
+
+namespace ddcn {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef double f64x2 __attribute__((ext_vector_type(2)));
+
+constexpr int ST = 256;
+constexpr int SC = 4;
+constexpr int SMAXCELLS = 8;
+constexpr unsigned SOOB = 0x80000000u;
+
+struct Tile9Args {
+    const float *gcol, *x, *offset, *mask;
+    float *gx, *goff, *gmask;
+    ddcn_geom g;
+    int P, cpg;
+    long ld;
+    int TH, TW, tiles_w, tiles, groups;
+    int CG, M;
+    int RH, RW, RS;
+};
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t s9_rsrc(const void *base, long bytes)
+{
+    const unsigned n = bytes <= 0 ? 0u : (bytes > 0x7fffffffL ? 0x7fffffffu : (unsigned)bytes);
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(base), 0, n, 0x00020000);
+}
+
+template <bool MOD, int NCELL>
+__global__ __launch_bounds__(ST, 2) void col2im_coord_tile9_kernel(Tile9Args a)
+{
+    constexpr int K2 = 9;
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    double *gs = reinterpret_cast<double *>(smem_raw);                       // [RS][4]
+    f32x4 *xs = reinterpret_cast<f32x4 *>(smem_raw + (size_t)a.RS * SC * 8);  // [RS]
+    const ddcn_geom &g = a.g;
+    const int t = threadIdx.x;
+
+    const int nwg = a.tiles * a.groups;
+    const int bid = blockIdx.x;
+    const int q = nwg >> 3, r8 = nwg & 7, xcd = bid & 7;
+    const int logical = (xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q) + (bid >> 3);
+    const int grp = logical / a.tiles, tile = logical - grp * a.tiles;
+
+    const int tyi = tile / a.tiles_w, txi = tile - tyi * a.tiles_w;
+    const int ty = t / a.TW, tx = t - ty * a.TW;
+    const int ho = tyi * a.TH + ty, wo = txi * a.TW + tx;
+    const bool live = ty < a.TH && ho < g.Ho && wo < g.Wo;
+    const int rh0 = tyi * a.TH * g.sh - g.ph - a.M;
+    const int rw0 = txi * a.TW * g.sw - g.pw - a.M;
+    const int n = blockIdx.z;
+    const int cg0 = grp * a.CG;
+    const int dgi = cg0 / a.cpg;
+    const int HW = g.H * g.W;
+    const int p = live ? ho * g.Wo + wo : 0;
+
+    const __amdgpu_buffer_rsrc_t rx = s9_rsrc(a.x + (long)n * g.C * HW, (long)g.C * HW * 4);
+    const __amdgpu_buffer_rsrc_t rgc = s9_rsrc(a.gcol + (long)n * g.C * K2 * a.ld, (long)g.C * K2 * a.ld * 4);
+    float *gxn = a.gx + (long)n * g.C * HW;
+
+    // patch cell i = t + 256*j -> byte offset inside one channel plane (out of image: rejected by the descriptor)
+    unsigned soff[NCELL];
+#pragma unroll
+    for (int j = 0; j < NCELL; ++j) {
+        const int i = t + ST * j;
+        const int rr = i / a.RW, rc = i - rr * a.RW;
+        const int y = rh0 + rr, xx = rw0 + rc;
+        soff[j] = (i < a.RS && y >= 0 && y < g.H && xx >= 0 && xx < g.W) ? (unsigned)((y * g.W + xx) * 4) : SOOB;
+    }
+
+    // per-tap sample state and running sums
+    int cell[K2];      // >= 0: patch cell of corner (hl, wl); -1: escapee; -2: sample outside (-1,H)x(-1,W)
+    float flh[K2], flw[K2], fm[K2];
+    float S1[K2], S2[K2], S3[K2], S4[K2];
+    int ghw[K2];
+    {
+        const float *off = a.offset + ((long)n * g.dg + dgi) * 2 * K2 * a.P + p;
+        const float *msk = MOD ? a.mask + ((long)n * g.dg + dgi) * K2 * a.P + p : nullptr;
+        const int h_in = ho * g.sh - g.ph, w_in = wo * g.sw - g.pw;
+#pragma unroll
+        for (int k = 0; k < K2; ++k) {
+            const int i = k / 3, j = k - 3 * i;
+            float h = -2.f, w = -2.f, m = 1.f;
+            if (live) {
+                h = (float)(h_in + i * g.dh) + off[(long)(2 * k) * a.P];
+                w = (float)(w_in + j * g.dw) + off[(long)(2 * k + 1) * a.P];
+                if (MOD) m = msk[(long)k * a.P];
+            }
+            const float fhl = floorf(h), fwl = floorf(w);
+            flh[k] = h - fhl; flw[k] = w - fwl; fm[k] = m;
+            const int hl = (int)fhl, wl = (int)fwl;
+            ghw[k] = (hl << 16) | (wl & 0xffff);
+            int c = -2;
+            if (live && h > -1.f && w > -1.f && h < (float)g.H && w < (float)g.W) {
+                const int rr = hl - rh0, rc = wl - rw0;
+                c = (rr >= 0 && rr + 1 < a.RH && rc >= 0 && rc + 1 < a.RW) ? rr * a.RW + rc : -1;
+            }
+            cell[k] = c;
+            S1[k] = S2[k] = S3[k] = S4[k] = 0.f;
+        }
+    }
+
+    float stg[NCELL][SC];
+    auto stage_load = [&](int c0) {
+#pragma unroll
+        for (int j = 0; j < NCELL; ++j)
+#pragma unroll
+            for (int cc = 0; cc < SC; ++cc)
+                stg[j][cc] = __builtin_bit_cast(
+                    float, __builtin_amdgcn_raw_buffer_load_b32(rx, soff[j], (unsigned)((c0 + cc) * HW * 4), 0));
+    };
+    auto stage_store = [&]() {
+#pragma unroll
+        for (int j = 0; j < NCELL; ++j) {
+            const int i = t + ST * j;
+            if (i < a.RS) xs[i] = f32x4{stg[j][0], stg[j][1], stg[j][2], stg[j][3]};
+        }
+    };
+
+    for (int i = t; i < a.RS * SC; i += ST) gs[i] = 0.0;
+    stage_load(cg0);
+    stage_store();
+    __syncthreads();
+
+    const unsigned pvo = live ? (unsigned)(p * 4) : SOOB;
+    const int nchunks = a.CG / SC;
+    for (int ch = 0; ch < nchunks; ++ch) {
+        const int c0 = cg0 + ch * SC;
+        // A. this chunk's 36 column values, and the next patch, go in flight together
+        float gcv[K2][SC];
+#pragma unroll
+        for (int k = 0; k < K2; ++k)
+#pragma unroll
+            for (int cc = 0; cc < SC; ++cc)
+                gcv[k][cc] = __builtin_bit_cast(
+                    float, __builtin_amdgcn_raw_buffer_load_b32(rgc, pvo, (unsigned)(((c0 + cc) * K2 + k) * a.ld * 4), 0));
+        if (ch + 1 < nchunks) stage_load(c0 + SC);
+        __builtin_amdgcn_sched_barrier(0);
+
+        // B. taps: gather x, accumulate the S sums, scatter into the LDS footprint
+#pragma unroll
+        for (int k = 0; k < K2; ++k) {
+            if (cell[k] >= 0) {
+                int ci = cell[k];
+                float lh = flh[k], lw = flw[k];
+                // keep the per-tap weights and addresses out of the loop-invariant hoist (they would cost 60 VGPRs)
+                asm volatile("" : "+v"(ci), "+v"(lh), "+v"(lw));
+                const f32x4 a1 = xs[ci], a2 = xs[ci + 1], a3 = xs[ci + a.RW], a4 = xs[ci + a.RW + 1];
+                const float hh = 1.f - lh, hw = 1.f - lw;
+                const float w1 = hh * hw, w2 = hh * lw, w3 = lh * hw, w4 = lh * lw;   // == K:133-140 weights
+                double *c1 = gs + ci * SC, *c3 = gs + (ci + a.RW) * SC;
+#pragma unroll
+                for (int cc = 0; cc < SC; ++cc) {
+                    const float gc = gcv[k][cc];
+                    S1[k] += gc * a1[cc]; S2[k] += gc * a2[cc]; S3[k] += gc * a3[cc]; S4[k] += gc * a4[cc];
+                    const float tg = MOD ? gc * fm[k] : gc;
+                    atomicAdd(c1 + cc, (double)(w1 * tg));
+                    atomicAdd(c1 + SC + cc, (double)(w2 * tg));
+                    atomicAdd(c3 + cc, (double)(w3 * tg));
+                    atomicAdd(c3 + SC + cc, (double)(w4 * tg));
+                }
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        __syncthreads();
+
+        // C. flush the footprint (one global atomic per touched in-image cell), re-zero, install the next patch
+#pragma unroll
+        for (int j = 0; j < NCELL; ++j) {
+            const int i = t + ST * j;
+            if (i < a.RS) {
+                f64x2 *cellp = reinterpret_cast<f64x2 *>(gs + i * SC);
+                const f64x2 v01 = cellp[0], v23 = cellp[1];
+                if (v01.x != 0.0 || v01.y != 0.0 || v23.x != 0.0 || v23.y != 0.0) {
+                    cellp[0] = f64x2{0.0, 0.0};
+                    cellp[1] = f64x2{0.0, 0.0};
+                    if (soff[j] != SOOB) {
+                        float *dst = gxn + (long)c0 * HW + (soff[j] >> 2);
+                        if (v01.x != 0.0) atomicAdd(dst, (float)v01.x);
+                        if (v01.y != 0.0) atomicAdd(dst + HW, (float)v01.y);
+                        if (v23.x != 0.0) atomicAdd(dst + 2 * HW, (float)v23.x);
+                        if (v23.y != 0.0) atomicAdd(dst + 3 * HW, (float)v23.y);
+                    }
+                }
+            }
+        }
+        if (ch + 1 < nchunks) stage_store();
+        __syncthreads();
+    }
+
+    if (!live) return;
+
+    // escapees: straight to global memory, whole channel group, same sums
+#pragma unroll
+    for (int k = 0; k < K2; ++k) {
+        if (cell[k] == -1) {
+            const int hl = ghw[k] >> 16, wl = (int)(short)(ghw[k] & 0xffff);
+            const bool ok1 = hl >= 0 && wl >= 0, ok2 = hl >= 0 && wl + 1 <= g.W - 1;
+            const bool ok3 = hl + 1 <= g.H - 1 && wl >= 0, ok4 = hl + 1 <= g.H - 1 && wl + 1 <= g.W - 1;
+            const int gi = hl * g.W + wl;
+            const float lh = flh[k], lw = flw[k];
+            const float hh = 1.f - lh, hw = 1.f - lw;
+            const float w1 = hh * hw, w2 = hh * lw, w3 = lh * hw, w4 = lh * lw;
+            const float *im = a.x + ((long)n * g.C + cg0) * HW + gi;
+            float *gim = gxn + (long)cg0 * HW + gi;
+            const float *gcp = a.gcol + (((long)n * g.C + cg0) * K2 + k) * a.ld + p;
+            for (int c = 0; c < a.CG; ++c) {
+                const float gc = gcp[(long)c * K2 * a.ld];
+                const float v1 = ok1 ? im[0] : 0.f;
+                const float v2 = ok2 ? im[1] : 0.f;
+                const float v3 = ok3 ? im[g.W] : 0.f;
+                const float v4 = ok4 ? im[g.W + 1] : 0.f;
+                S1[k] += gc * v1; S2[k] += gc * v2; S3[k] += gc * v3; S4[k] += gc * v4;
+                const float tg = MOD ? gc * fm[k] : gc;
+                if (ok1) atomicAdd(gim, w1 * tg);
+                if (ok2) atomicAdd(gim + 1, w2 * tg);
+                if (ok3) atomicAdd(gim + g.W, w3 * tg);
+                if (ok4) atomicAdd(gim + g.W + 1, w4 * tg);
+                im += HW; gim += HW;
+            }
+        }
+    }
+
+    // grad_offset / grad_mask from the sums (K:163-184 coordinate weights, K:752 mask gradient)
+    float *goffb = a.goff + ((long)n * g.dg + dgi) * 2 * K2 * a.P + p;
+    float *gmaskb = MOD ? a.gmask + ((long)n * g.dg + dgi) * K2 * a.P + p : nullptr;
+#pragma unroll
+    for (int k = 0; k < K2; ++k) {
+        if (cell[k] != -2) {
+            const float lh = flh[k], lw = flw[k];
+            const float hh = 1.f - lh, hw = 1.f - lw;
+            float gh = (-1.f * hw * S1[k]) + (-1.f * lw * S2[k]) + hw * S3[k] + lw * S4[k];
+            float gw = (-1.f * hh * S1[k]) + hh * S2[k] + (-1.f * lh * S3[k]) + lh * S4[k];
+            if (MOD) { gh *= fm[k]; gw *= fm[k]; }
+            atomicAdd(goffb + (long)(2 * k) * a.P, gh);
+            atomicAdd(goffb + (long)(2 * k + 1) * a.P, gw);
+            if (MOD) atomicAdd(gmaskb + (long)k * a.P, hh * hw * S1[k] + hh * lw * S2[k] + lh * hw * S3[k] + lh * lw * S4[k]);
+        }
+    }
+}
+
+int launch_col2im_coord_tile9(const float *gcol, const float *x, const float *offset, const float *mask, float *gx,
+                              float *goff, float *gmask, const ddcn_geom &g, hipStream_t stream, bool *handled)
+{
+    *handled = false;
+    const Dims d = dims_of(g);
+    if (g.kh != 3 || g.kw != 3) return DDCN_OK;
+    if (g.H >= 32766 || g.W >= 32766 || d.cpg % SC) return DDCN_OK;
+    if ((long)g.C * d.K2 * d.ld * 4 >= (1L << 31) || (long)g.C * g.H * g.W * 4 >= (1L << 31)) return DDCN_OK;
+    static const int env_on = getenv("DDCN_SCATTER9") ? atoi(getenv("DDCN_SCATTER9")) : 1;
+    if (!env_on) return DDCN_OK;
+    Tile9Args a{};
+    int TW;
+    if (g.Wo <= 32) {
+        TW = g.Wo;
+    } else {
+        int best = 32, waste = (g.Wo + 31) / 32 * 32 - g.Wo;
+        for (int w = 31; w >= 16; --w) {
+            const int ws = (g.Wo + w - 1) / w * w - g.Wo;
+            if (ws < waste) { waste = ws; best = w; }
+        }
+        TW = best;
+    }
+    int TH = ST / TW;
+    if (TH > g.Ho) TH = g.Ho;
+    a.TW = TW; a.TH = TH;
+    a.tiles_w = (g.Wo + TW - 1) / TW;
+    a.tiles = a.tiles_w * ((g.Ho + TH - 1) / TH);
+    static const int env_m = getenv("DDCN_TILE_MARGIN") ? atoi(getenv("DDCN_TILE_MARGIN")) : 6;
+    static const int env_cg = getenv("DDCN_SCATTER_CG") ? atoi(getenv("DDCN_SCATTER_CG")) : 0;
+    bool ok = false;
+    for (int M = env_m; M >= 0 && !ok; M -= 2) {
+        const int RH = (TH - 1) * g.sh + 2 * g.dh + 2 + 2 * M;
+        const int RW = (TW - 1) * g.sw + 2 * g.dw + 2 + 2 * M;
+        if (RH * RW <= SMAXCELLS * ST && (size_t)RH * RW * 48 <= 76 * 1024) {
+            a.M = M; a.RH = RH; a.RW = RW; a.RS = RH * RW;
+            ok = true;
+        }
+    }
+    if (!ok) return DDCN_OK;
+    int CG = d.cpg;
+    while (CG % (2 * SC) == 0 && (long)a.tiles * g.N * (g.C / CG) < 1024) CG /= 2;
+    if (env_cg > 0 && d.cpg % env_cg == 0 && env_cg % SC == 0) CG = env_cg;
+    a.CG = CG;
+    a.groups = g.C / CG;
+    *handled = true;
+    a.gcol = gcol; a.x = x; a.offset = offset; a.mask = mask; a.gx = gx; a.goff = goff; a.gmask = gmask;
+    a.g = g; a.P = d.P; a.cpg = d.cpg; a.ld = d.ld;
+    const long nwg = (long)a.tiles * a.groups;
+    if (nwg > 0x7fffffffL || g.N > 65535) return fail(DDCN_ERR_UNSUPPORTED, "col2im_coord_tile9: grid too large");
+    dim3 grid((unsigned)nwg, 1, g.N);
+    const size_t smem = (size_t)a.RS * 48;
+    const int ncell = (a.RS + ST - 1) / ST;
+    hipError_t e = hipSuccess;
+#define DDCN_S9_LAUNCH(NC)                                                                                       \
+    do {                                                                                                         \
+        const void *fn = mask ? (const void *)&col2im_coord_tile9_kernel<true, NC>                               \
+                              : (const void *)&col2im_coord_tile9_kernel<false, NC>;                             \
+        e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);                      \
+        if (e != hipSuccess) break;                                                                              \
+        if (mask)                                                                                                \
+            hipLaunchKernelGGL((col2im_coord_tile9_kernel<true, NC>), grid, dim3(ST), smem, stream, a);          \
+        else                                                                                                     \
+            hipLaunchKernelGGL((col2im_coord_tile9_kernel<false, NC>), grid, dim3(ST), smem, stream, a);         \
+    } while (0)
+    if (ncell <= 2) DDCN_S9_LAUNCH(2);
+    else if (ncell <= 4) DDCN_S9_LAUNCH(4);
+    else if (ncell <= 6) DDCN_S9_LAUNCH(6);
+    else DDCN_S9_LAUNCH(8);
+#undef DDCN_S9_LAUNCH
+    if (e != hipSuccess) return fail(DDCN_ERR_LAUNCH, "col2im_coord_tile9: hipFuncSetAttribute: %s", hipGetErrorString(e));
+    return check_launch("col2im_coord_tile9");
+}
+
+}  // namespace ddcn
