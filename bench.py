@@ -58,7 +58,7 @@ def make_inputs(w, dev, seed):
     K = C * 9
     x = torch.randn(N, C, H, W, generator=g)
     weight = (torch.rand(w["Co"], C, 3, 3, generator=g) * 2 - 1) / (K ** 0.5)
-    offset = torch.randn(N, 18, H, W, generator=g) * 2
+    offset = torch.randn(N, 18, H, W, generator=g) * w.get("offstd", 2)
     mask = torch.sigmoid(torch.randn(N, 9, H, W, generator=g))
     gout = torch.randn(N, w["Co"], H, W, generator=g)
     return [t.to(dev) for t in (x, weight, offset, mask, gout)]

@@ -25,7 +25,9 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef double f64x2 __attribute__((ext_vector_type(2)));
 
 constexpr int ST = 256;
-constexpr int SC = 4;
+#ifndef DDCN_S9_WPS
+#define DDCN_S9_WPS 3
+#endif
 constexpr int SMAXCELLS = 8;
 constexpr unsigned SOOB = 0x80000000u;
 
@@ -46,13 +48,14 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t s9_rsrc(const void *base, long
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(base), 0, n, 0x00020000);
 }
 
-template <bool MOD, int NCELL>
-__global__ __launch_bounds__(ST, 2) void col2im_coord_tile9_kernel(Tile9Args a)
+template <bool MOD, int NCELL, int SC>
+__global__ __launch_bounds__(ST, SC == 4 ? 2 : DDCN_S9_WPS) void col2im_coord_tile9_kernel(Tile9Args a)
 {
+    typedef float xvec __attribute__((ext_vector_type(SC)));
     constexpr int K2 = 9;
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    double *gs = reinterpret_cast<double *>(smem_raw);                       // [RS][4]
-    f32x4 *xs = reinterpret_cast<f32x4 *>(smem_raw + (size_t)a.RS * SC * 8);  // [RS]
+    double *gs = reinterpret_cast<double *>(smem_raw);                       // [SC][RS]: a wave's 64 cells -> 128 banks
+    xvec *xs = reinterpret_cast<xvec *>(smem_raw + (size_t)a.RS * SC * 8);    // [RS][SC]
     const ddcn_geom &g = a.g;
     const int t = threadIdx.x;
 
@@ -133,7 +136,12 @@ __global__ __launch_bounds__(ST, 2) void col2im_coord_tile9_kernel(Tile9Args a)
 #pragma unroll
         for (int j = 0; j < NCELL; ++j) {
             const int i = t + ST * j;
-            if (i < a.RS) xs[i] = f32x4{stg[j][0], stg[j][1], stg[j][2], stg[j][3]};
+            if (i < a.RS) {
+                xvec v;
+#pragma unroll
+                for (int cc = 0; cc < SC; ++cc) v[cc] = stg[j][cc];
+                xs[i] = v;
+            }
         }
     };
 
@@ -144,17 +152,20 @@ __global__ __launch_bounds__(ST, 2) void col2im_coord_tile9_kernel(Tile9Args a)
 
     const unsigned pvo = live ? (unsigned)(p * 4) : SOOB;
     const int nchunks = a.CG / SC;
+    // column values of the current chunk; each tap reloads its registers for the next chunk as soon as it is done
+    float gcv[K2][SC];
+#pragma unroll
+    for (int k = 0; k < K2; ++k)
+#pragma unroll
+        for (int cc = 0; cc < SC; ++cc)
+            gcv[k][cc] = __builtin_bit_cast(
+                float, __builtin_amdgcn_raw_buffer_load_b32(rgc, pvo, (unsigned)(((cg0 + cc) * K2 + k) * a.ld * 4), 0));
     for (int ch = 0; ch < nchunks; ++ch) {
         const int c0 = cg0 + ch * SC;
-        // A. this chunk's 36 column values, and the next patch, go in flight together
-        float gcv[K2][SC];
-#pragma unroll
-        for (int k = 0; k < K2; ++k)
-#pragma unroll
-            for (int cc = 0; cc < SC; ++cc)
-                gcv[k][cc] = __builtin_bit_cast(
-                    float, __builtin_amdgcn_raw_buffer_load_b32(rgc, pvo, (unsigned)(((c0 + cc) * K2 + k) * a.ld * 4), 0));
-        if (ch + 1 < nchunks) stage_load(c0 + SC);
+        const bool more = ch + 1 < nchunks;
+        const unsigned pvn = more ? pvo : SOOB;
+        // A. the next patch goes in flight
+        if (more) stage_load(c0 + SC);
         __builtin_amdgcn_sched_barrier(0);
 
         // B. taps: gather x, accumulate the S sums, scatter into the LDS footprint
@@ -165,23 +176,27 @@ __global__ __launch_bounds__(ST, 2) void col2im_coord_tile9_kernel(Tile9Args a)
                 float lh = flh[k], lw = flw[k];
                 // keep the per-tap weights and addresses out of the loop-invariant hoist (they would cost 60 VGPRs)
                 asm volatile("" : "+v"(ci), "+v"(lh), "+v"(lw));
-                const f32x4 a1 = xs[ci], a2 = xs[ci + 1], a3 = xs[ci + a.RW], a4 = xs[ci + a.RW + 1];
+                const xvec a1 = xs[ci], a2 = xs[ci + 1], a3 = xs[ci + a.RW], a4 = xs[ci + a.RW + 1];
                 const float hh = 1.f - lh, hw = 1.f - lw;
                 const float w1 = hh * hw, w2 = hh * lw, w3 = lh * hw, w4 = lh * lw;   // == K:133-140 weights
-                double *c1 = gs + ci * SC, *c3 = gs + (ci + a.RW) * SC;
+                double *c1 = gs + ci, *c3 = gs + ci + a.RW;
 #pragma unroll
                 for (int cc = 0; cc < SC; ++cc) {
                     const float gc = gcv[k][cc];
                     S1[k] += gc * a1[cc]; S2[k] += gc * a2[cc]; S3[k] += gc * a3[cc]; S4[k] += gc * a4[cc];
                     const float tg = MOD ? gc * fm[k] : gc;
-                    atomicAdd(c1 + cc, (double)(w1 * tg));
-                    atomicAdd(c1 + SC + cc, (double)(w2 * tg));
-                    atomicAdd(c3 + cc, (double)(w3 * tg));
-                    atomicAdd(c3 + SC + cc, (double)(w4 * tg));
+                    atomicAdd(c1 + cc * a.RS, (double)(w1 * tg));
+                    atomicAdd(c1 + cc * a.RS + 1, (double)(w2 * tg));
+                    atomicAdd(c3 + cc * a.RS, (double)(w3 * tg));
+                    atomicAdd(c3 + cc * a.RS + 1, (double)(w4 * tg));
                 }
             }
+#pragma unroll
+            for (int cc = 0; cc < SC; ++cc)
+                gcv[k][cc] = __builtin_bit_cast(
+                    float, __builtin_amdgcn_raw_buffer_load_b32(rgc, pvn, (unsigned)(((c0 + SC + cc) * K2 + k) * a.ld * 4), 0));
+            __builtin_amdgcn_sched_barrier(0);
         }
-        __builtin_amdgcn_sched_barrier(0);
         __syncthreads();
 
         // C. flush the footprint (one global atomic per touched in-image cell), re-zero, install the next patch
@@ -189,22 +204,21 @@ __global__ __launch_bounds__(ST, 2) void col2im_coord_tile9_kernel(Tile9Args a)
         for (int j = 0; j < NCELL; ++j) {
             const int i = t + ST * j;
             if (i < a.RS) {
-                f64x2 *cellp = reinterpret_cast<f64x2 *>(gs + i * SC);
-                const f64x2 v01 = cellp[0], v23 = cellp[1];
-                if (v01.x != 0.0 || v01.y != 0.0 || v23.x != 0.0 || v23.y != 0.0) {
-                    cellp[0] = f64x2{0.0, 0.0};
-                    cellp[1] = f64x2{0.0, 0.0};
-                    if (soff[j] != SOOB) {
-                        float *dst = gxn + (long)c0 * HW + (soff[j] >> 2);
-                        if (v01.x != 0.0) atomicAdd(dst, (float)v01.x);
-                        if (v01.y != 0.0) atomicAdd(dst + HW, (float)v01.y);
-                        if (v23.x != 0.0) atomicAdd(dst + 2 * HW, (float)v23.x);
-                        if (v23.y != 0.0) atomicAdd(dst + 3 * HW, (float)v23.y);
+                double v[SC];
+                bool any = false;
+#pragma unroll
+                for (int cc = 0; cc < SC; ++cc) { v[cc] = gs[i + cc * a.RS]; any |= v[cc] != 0.0; }
+                if (any) {
+                    float *dst = gxn + (long)c0 * HW + (soff[j] >> 2);
+#pragma unroll
+                    for (int cc = 0; cc < SC; ++cc) {
+                        gs[i + cc * a.RS] = 0.0;
+                        if (soff[j] != SOOB && v[cc] != 0.0) atomicAdd(dst + cc * HW, (float)v[cc]);
                     }
                 }
             }
         }
-        if (ch + 1 < nchunks) stage_store();
+        if (more) stage_store();
         __syncthreads();
     }
 
@@ -265,6 +279,8 @@ int launch_col2im_coord_tile9(const float *gcol, const float *x, const float *of
     *handled = false;
     const Dims d = dims_of(g);
     if (g.kh != 3 || g.kw != 3) return DDCN_OK;
+    static const int SC = getenv("DDCN_SCATTER_SC") ? atoi(getenv("DDCN_SCATTER_SC")) : 4;
+    if (SC != 2 && SC != 4) return DDCN_OK;
     if (g.H >= 32766 || g.W >= 32766 || d.cpg % SC) return DDCN_OK;
     if ((long)g.C * d.K2 * d.ld * 4 >= (1L << 31) || (long)g.C * g.H * g.W * 4 >= (1L << 31)) return DDCN_OK;
     static const int env_on = getenv("DDCN_SCATTER9") ? atoi(getenv("DDCN_SCATTER9")) : 1;
@@ -292,7 +308,7 @@ int launch_col2im_coord_tile9(const float *gcol, const float *x, const float *of
     for (int M = env_m; M >= 0 && !ok; M -= 2) {
         const int RH = (TH - 1) * g.sh + 2 * g.dh + 2 + 2 * M;
         const int RW = (TW - 1) * g.sw + 2 * g.dw + 2 + 2 * M;
-        if (RH * RW <= SMAXCELLS * ST && (size_t)RH * RW * 48 <= 76 * 1024) {
+        if (RH * RW <= SMAXCELLS * ST && (size_t)RH * RW * 12 * SC <= (size_t)(SC == 4 ? 80 : 40) * 1024) {
             a.M = M; a.RH = RH; a.RW = RW; a.RS = RH * RW;
             ok = true;
         }
@@ -309,24 +325,28 @@ int launch_col2im_coord_tile9(const float *gcol, const float *x, const float *of
     const long nwg = (long)a.tiles * a.groups;
     if (nwg > 0x7fffffffL || g.N > 65535) return fail(DDCN_ERR_UNSUPPORTED, "col2im_coord_tile9: grid too large");
     dim3 grid((unsigned)nwg, 1, g.N);
-    const size_t smem = (size_t)a.RS * 48;
+    const size_t smem = (size_t)a.RS * 12 * SC;
     const int ncell = (a.RS + ST - 1) / ST;
     hipError_t e = hipSuccess;
+#define DDCN_S9_LAUNCH2(MOD, NC, SCV)                                                                            \
+    do {                                                                                                         \
+        e = hipFuncSetAttribute((const void *)&col2im_coord_tile9_kernel<MOD, NC, SCV>,                          \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);                          \
+        if (e == hipSuccess)                                                                                     \
+            hipLaunchKernelGGL((col2im_coord_tile9_kernel<MOD, NC, SCV>), grid, dim3(ST), smem, stream, a);      \
+    } while (0)
 #define DDCN_S9_LAUNCH(NC)                                                                                       \
     do {                                                                                                         \
-        const void *fn = mask ? (const void *)&col2im_coord_tile9_kernel<true, NC>                               \
-                              : (const void *)&col2im_coord_tile9_kernel<false, NC>;                             \
-        e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);                      \
-        if (e != hipSuccess) break;                                                                              \
-        if (mask)                                                                                                \
-            hipLaunchKernelGGL((col2im_coord_tile9_kernel<true, NC>), grid, dim3(ST), smem, stream, a);          \
-        else                                                                                                     \
-            hipLaunchKernelGGL((col2im_coord_tile9_kernel<false, NC>), grid, dim3(ST), smem, stream, a);         \
+        if (mask && SC == 4) DDCN_S9_LAUNCH2(true, NC, 4);                                                       \
+        else if (mask) DDCN_S9_LAUNCH2(true, NC, 2);                                                             \
+        else if (SC == 4) DDCN_S9_LAUNCH2(false, NC, 4);                                                         \
+        else DDCN_S9_LAUNCH2(false, NC, 2);                                                                      \
     } while (0)
     if (ncell <= 2) DDCN_S9_LAUNCH(2);
     else if (ncell <= 4) DDCN_S9_LAUNCH(4);
     else if (ncell <= 6) DDCN_S9_LAUNCH(6);
     else DDCN_S9_LAUNCH(8);
+#undef DDCN_S9_LAUNCH2
 #undef DDCN_S9_LAUNCH
     if (e != hipSuccess) return fail(DDCN_ERR_LAUNCH, "col2im_coord_tile9: hipFuncSetAttribute: %s", hipGetErrorString(e));
     return check_launch("col2im_coord_tile9");
