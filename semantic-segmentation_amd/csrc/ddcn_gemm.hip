@@ -16,6 +16,8 @@
 // range, never by control flow -- the first version of this kernel guarded each load with a
 // branch, which split the loop into load / MFMA / store phases that the two waves of a SIMD
 // executed in lockstep (rocprofv3: matrix pipe 49-60 % busy, 5 VALU per MFMA).
+#include <stdlib.h>
+
 #include "ddcn_common.h"
 
 namespace ddcn {
@@ -23,10 +25,10 @@ namespace ddcn {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) float lds_float;
 
 constexpr int BM = 128, BN = 128, BK = 32, NT = 256;
-constexpr int LD_MN = 128;   // LDS row stride for operands stored [k][mn] in memory (b128 writes)
-constexpr int LD_KC = 129;   // LDS row stride for operands stored [mn][k] in memory (transposing b32 writes)
+constexpr int BN_TAIL = 32;  // narrow column tiles that fill the last, partial round of workgroups
 constexpr unsigned OOB = 0x80000000u;   // per-lane offset that every descriptor below rejects (reads 0, drops stores)
 
 struct GemmArgs {
@@ -36,14 +38,21 @@ struct GemmArgs {
     long lda, ldb, ldc;
     long sA0, sA1, sB0, sB1, sC0, sC1;   // batch strides: z0 (image), z1 (weight group)
     long nA, nB, nC;          // elements of one (z0, z1) slice of A / B / C (descriptor bounds)
-    int nz1, ksplit, kchunk;  // grid.z = nz0 * nz1 * ksplit ; kchunk multiple of BK
-    int tiles_m, tiles_n;
+    int nz1, ksplit, kchunk;  // nz = nz0 * nz1 * ksplit slices ; kchunk multiple of BK
+    int tiles_m;
+    int nb, nn;               // column tiles per slice: nb of width BN, then nn of width BN_TAIL
+    int total_big, total_nar;    // tiles_m * nb * nz wide tiles, tiles_m * nn * nz narrow tiles
+    int blocks_big, blocks_nar;  // workgroups per class: two tiles (one per wave group) each
 };
 
+// Descriptor over [base, base + elems_left) floats, clamped to [0, 2 GiB).  32-bit scalar compares only: a 64-bit
+// ordered compare has no SALU form and would put VALU work into the memory phase of the K loop (see gemm_tile).
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const float *base, long elems_left)
 {
-    const long bytes = elems_left * 4;
-    const unsigned n = bytes <= 0 ? 0u : (bytes > 0x7fffffffL ? 0x7fffffffu : (unsigned)bytes);
+    int hi = (int)(elems_left >> 32);
+    unsigned lo = (unsigned)elems_left;
+    asm("" : "+s"(hi), "+s"(lo));   // or instcombine folds the tests back into 64-bit compares (v_cmp_*_i64)
+    const unsigned n = hi < 0 ? 0u : ((hi > 0 || lo >= (1u << 29)) ? 0x7fffffffu : lo * 4u);
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(base), 0, n, 0x00020000);
 }
 
@@ -52,84 +61,121 @@ __device__ __forceinline__ f32x4 bload4(__amdgpu_buffer_rsrc_t r, unsigned voff)
     return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, 0, 0));
 }
 
-// ---- operand stored [K][MN] in memory (mn contiguous): tile [BK][128]; thread: float4 column c4, rows row+8i
+// ---- operand stored [K][MN] in memory (mn contiguous): tile [BK][EXT]; thread: float4 column c4, rows row + RSTEP*i.
+// LDS image [k][mn], row stride EXT (b128 writes).
+template <int EXT>
 struct LoaderMN {
-    unsigned voff[4];
-    int row, c4;
-    __device__ __forceinline__ void init(long ld, int mn0, int t)
+    static constexpr int NV = EXT / 32, TPR = EXT / 4, RSTEP = NT / TPR, LD = EXT;
+    unsigned voff[NV];
+    float *dst;
+    __device__ __forceinline__ void init(float *lds, long ld, int mn0, int, int t)
     {
-        c4 = (t & 31) * 4;
-        row = t >> 5;
+        const int c4 = (t % TPR) * 4, row = t / TPR;
+        dst = lds + row * LD + c4;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) voff[i] = (unsigned)(((long)(row + 8 * i) * ld + mn0 + c4) * 4);
+        for (int i = 0; i < NV; ++i) voff[i] = (unsigned)(((long)(row + RSTEP * i) * ld + mn0 + c4) * 4);
     }
-    // base: slice pointer advanced to row k0; kvalid = valid rows in this tile
-    __device__ __forceinline__ void load(__amdgpu_buffer_rsrc_t r, int kvalid, f32x4 (&v)[4]) const
+    __device__ __forceinline__ static long origin(long ld, int, int k0) { return (long)k0 * ld; }
+    // elements from the tile origin to the end of the valid rows [k0, kend): the K edge is the descriptor's bound
+    __device__ __forceinline__ static long extent(long ld, long slice_left, int kvalid)
     {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) v[i] = bload4(r, (row + 8 * i < kvalid) ? voff[i] : OOB);
+        const long rows = (long)kvalid * ld;
+        int sign = (int)((rows - slice_left) >> 32);   // min() through a 32-bit sign test (SALU)
+        asm("" : "+s"(sign));
+        return sign < 0 ? rows : slice_left;
     }
-    __device__ __forceinline__ void store(float *s, const f32x4 (&v)[4], int) const
+    // descriptor base: slice pointer advanced to row k0
+    __device__ __forceinline__ void load(__amdgpu_buffer_rsrc_t r, f32x4 (&v)[NV]) const
     {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) *reinterpret_cast<f32x4 *>(s + (row + 8 * i) * LD_MN + c4) = v[i];
+        for (int i = 0; i < NV; ++i) v[i] = bload4(r, voff[i]);
+    }
+    __device__ __forceinline__ void store(const f32x4 (&v)[NV], int) const
+    {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) *reinterpret_cast<f32x4 *>(dst + RSTEP * i * LD) = v[i];
     }
 };
 
-// ---- operand stored [MN][K] in memory (k contiguous): tile [128][BK]; thread: float4 k4, rows row+32i; transposed into LDS
+// ---- operand stored [MN][K] in memory (k contiguous): tile [EXT][BK]; thread: float4 k4, rows row + 32i.
+// Transposed into the same [k][mn] LDS image, row stride EXT + 1 (conflict-free b32 writes).
+template <int EXT>
 struct LoaderKC {
-    unsigned voff[4];
-    int k4, row;
-    __device__ __forceinline__ void init(long ld, int mn0, int mnlim, int t)
+    static constexpr int NV = EXT / 32, LD = EXT + 1;
+    unsigned voff[NV];
+    int k4;
+    lds_float *d0, *d2;   // LDS rows k4 and k4 + 2 of this thread's column: every ds_write2_b32 offset (<= 1020 B) is
+                      // reachable from one of them, so the K loop needs no address arithmetic (no VALU)
+    __device__ __forceinline__ void init(float *lds, long ld, int mn0, int mnlim, int t)
     {
         k4 = (t & 7) * 4;
-        row = t >> 3;
+        const int row = t >> 3;
+        d0 = (lds_float *)lds + k4 * LD + row;
+        d2 = d0 + 2 * LD;
+        asm volatile("" : "+v"(d2));   // a real register, not "d0 + const" rematerialised inside the loop
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < NV; ++i)
             voff[i] = (mn0 + row + 32 * i < mnlim) ? (unsigned)(((long)(row + 32 * i) * ld + k4) * 4) : OOB;
     }
-    // base: slice pointer advanced to (row mn0, column k0).  Issue only: the K-edge masking (elements with
-    // k4 + j >= kvalid must be zero) is applied in store(), so nothing waits on the loads before the MFMAs.
-    __device__ __forceinline__ void load(__amdgpu_buffer_rsrc_t r, int, f32x4 (&v)[4]) const
+    __device__ __forceinline__ static long origin(long ld, int mn0, int k0) { return (long)mn0 * ld + k0; }
+    __device__ __forceinline__ static long extent(long, long slice_left, int) { return slice_left; }
+    // descriptor base: slice pointer advanced to (row mn0, column k0).  The K edge cuts through rows here, so it is
+    // applied in store(): elements with k4 + j >= kvalid are written as zero.
+    __device__ __forceinline__ void load(__amdgpu_buffer_rsrc_t r, f32x4 (&v)[NV]) const
     {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) v[i] = bload4(r, voff[i]);
+        for (int i = 0; i < NV; ++i) v[i] = bload4(r, voff[i]);
     }
-    __device__ __forceinline__ void store(float *s, const f32x4 (&v)[4], int kvalid) const
+    __device__ __forceinline__ void store(const f32x4 (&v)[NV], int kvalid) const
     {
+        if (kvalid >= BK) {   // uniform; the full tiles carry no VALU work at all
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            float *d = s + k4 * LD_KC + row + 32 * i;
-            d[0] = (k4 + 0 < kvalid) ? v[i].x : 0.f;
-            d[LD_KC] = (k4 + 1 < kvalid) ? v[i].y : 0.f;
-            d[2 * LD_KC] = (k4 + 2 < kvalid) ? v[i].z : 0.f;
-            d[3 * LD_KC] = (k4 + 3 < kvalid) ? v[i].w : 0.f;
+            for (int i = 0; i < NV; ++i) {
+                d0[32 * i] = v[i].x; d0[LD + 32 * i] = v[i].y; d2[32 * i] = v[i].z; d2[LD + 32 * i] = v[i].w;
+            }
+            asm volatile("; full tile" ::: "memory");   // keeps hipcc from merging the two paths into one with selects
+        } else {
+#pragma unroll
+            for (int i = 0; i < NV; ++i) {
+                d0[32 * i] = (k4 + 0 < kvalid) ? v[i].x : 0.f;
+                d0[LD + 32 * i] = (k4 + 1 < kvalid) ? v[i].y : 0.f;
+                d2[32 * i] = (k4 + 2 < kvalid) ? v[i].z : 0.f;
+                d2[LD + 32 * i] = (k4 + 3 < kvalid) ? v[i].w : 0.f;
+            }
+            asm volatile("; edge tile" ::: "memory");
         }
     }
 };
 
-template <bool A_KC, bool B_KC, bool ATOMIC>
-__global__ __launch_bounds__(NT) void gemm_f32_mfma(GemmArgs a)
+template <bool KC, int EXT> struct LoaderSel { typedef LoaderMN<EXT> type; };
+template <int EXT> struct LoaderSel<true, EXT> { typedef LoaderKC<EXT> type; };
+
+// XCD-aware order inside a class of `count` workgroups: they are dealt round-robin over the 8 XCDs, so give each
+// XCD a contiguous run of the logical order (bijective for any count).
+__device__ __forceinline__ int xcd_order(int b, int count)
 {
-    constexpr int LDA = A_KC ? LD_KC : LD_MN;
-    constexpr int LDB = B_KC ? LD_KC : LD_MN;
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    float *As0 = smem, *Bs0 = smem + 2 * BK * LDA;
+    const int q = count >> 3, r = count & 7, xcd = b & 7;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
+}
 
-    const int t = threadIdx.x;
+// One BM x BNT output tile of slice z, computed by one wave group (4 waves as WAVES_M x WAVES_N) of a
+// two-group workgroup.  Every s_barrier below is executed by BOTH groups the same number of times.
+template <bool A_KC, bool B_KC, bool ATOMIC, int BNT>
+__device__ __forceinline__ void gemm_tile(const GemmArgs &a, float *smem, int grp, bool valid, int z, int tile_m, int n0)
+{
+    typedef typename LoaderSel<A_KC, BM>::type LA;
+    typedef typename LoaderSel<B_KC, BNT>::type LB;
+    constexpr int LDA = LA::LD, LDB = LB::LD;
+    constexpr int WN_ = BNT >= 128 ? 64 : 32;          // columns per wave
+    constexpr int WAVES_N = BNT / WN_, WAVES_M = 4 / WAVES_N;
+    constexpr int WM_ = BM / WAVES_M;                  // rows per wave
+    constexpr int MI = WM_ / 32, NJ = WN_ / 32;
+    float *As = smem + grp * (BK * LDA + BK * LDB), *Bs = As + BK * LDA;   // one private buffer per group
+
+    const int t = threadIdx.x & (NT - 1);
     const int lane = t & 63, wave = t >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = wave / WAVES_N, wn = wave % WAVES_N;
 
-    // XCD-aware tile order: workgroups are dealt round-robin over the 8 XCDs, so give each XCD a contiguous
-    // run of the logical order (bijective for any count), with the m tile fastest: the workgroups that
-    // share a B (columns) tile then run back to back on one XCD and hit its L2.
-    const int nwg = a.tiles_m * a.tiles_n;
-    const int bid = blockIdx.x;
-    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
-    const int logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
-    const int tile_n = logical / a.tiles_m, tile_m = logical - tile_n * a.tiles_m;
-
-    int z = blockIdx.z;
     const int split = z % a.ksplit;
     z /= a.ksplit;
     const int z1 = z % a.nz1, z0 = z / a.nz1;
@@ -137,114 +183,135 @@ __global__ __launch_bounds__(NT) void gemm_f32_mfma(GemmArgs a)
     const float *B = a.B + z0 * a.sB0 + z1 * a.sB1;
     float *C = a.C + z0 * a.sC0 + z1 * a.sC1;
 
-    const int m0 = tile_m * BM, n0 = tile_n * BN;
+    const int m0 = tile_m * BM;
     const int kbeg = split * a.kchunk;
     const int kend = min(a.K, kbeg + a.kchunk);
-    const int ntiles = (kend - kbeg + BK - 1) / BK;
+    const int ntiles = a.kchunk / BK;   // the same for every group of the launch (short last splits read zeros)
+    // an idle group (odd tile count) runs the same loop on empty descriptors: loads return 0, stores are dropped
+    const long nA = valid ? a.nA : 0, nB = valid ? a.nB : 0, nC = valid ? a.nC : 0;
 
-    f32x16 acc[2][2];
+    f32x16 acc[MI][NJ];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < MI; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < NJ; ++j)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-    LoaderKC lak; LoaderMN lam; LoaderKC lbk; LoaderMN lbm;
-    if (A_KC) lak.init(a.lda, m0, a.M, t); else lam.init(a.lda, m0, t);
-    if (B_KC) lbk.init(a.ldb, n0, a.N, t); else lbm.init(a.ldb, n0, t);
-    f32x4 ra[4], rb[4];
+    LA la; LB lb;
+    la.init(As, a.lda, m0, a.M, t);
+    lb.init(Bs, a.ldb, n0, a.N, t);
+    f32x4 ra[LA::NV], rb[LB::NV];
 
     auto gload = [&](int k0) {
-        const int kvalid = kend - k0;   // <= 0 past the end: every lane reads zeros
-        if (A_KC) {
-            const long o = (long)m0 * a.lda + k0;
-            lak.load(make_rsrc(A + o, a.nA - o), kvalid, ra);
-        } else {
-            const long o = (long)k0 * a.lda;
-            lam.load(make_rsrc(A + o, a.nA - o), kvalid, ra);
-        }
-        if (B_KC) {
-            const long o = (long)n0 * a.ldb + k0;
-            lbk.load(make_rsrc(B + o, a.nB - o), kvalid, rb);
-        } else {
-            const long o = (long)k0 * a.ldb;
-            lbm.load(make_rsrc(B + o, a.nB - o), kvalid, rb);
-        }
+        const int kvalid = max(kend - k0, 0);   // 0 past the end: [K][MN] operands read zeros, [MN][K] ones are masked in store()
+        const long oa = LA::origin(a.lda, m0, k0), ob = LB::origin(a.ldb, n0, k0);
+        la.load(make_rsrc(A + oa, LA::extent(a.lda, nA - oa, kvalid)), ra);
+        lb.load(make_rsrc(B + ob, LB::extent(a.ldb, nB - ob, kvalid)), rb);
     };
-    auto sstore = [&](int buf, int k0) {
+    auto sstore = [&](int k0) {
         const int kvalid = kend - k0;
-        if (A_KC) lak.store(As0 + buf * (BK * LDA), ra, kvalid); else lam.store(As0 + buf * (BK * LDA), ra, kvalid);
-        if (B_KC) lbk.store(Bs0 + buf * (BK * LDB), rb, kvalid); else lbm.store(Bs0 + buf * (BK * LDB), rb, kvalid);
+        la.store(ra, kvalid);
+        lb.store(rb, kvalid);
     };
 
     gload(kbeg);
-    sstore(0, kbeg);
+    sstore(kbeg);
+    gload(kbeg + BK);
     __syncthreads();
+    // Ping-pong: the two groups alternate between a compute phase (ds_read + MFMA from the private buffer) and a
+    // short memory phase (the prefetched registers -> LDS, next loads issued), one barrier apart, so that each SIMD
+    // always has one wave in its MFMA stream.  Two independent 256-thread workgroups per CU ran in lockstep
+    // instead: both waves of a SIMD reached their loads / LDS writes / barrier together and the matrix pipe idled.
+    // The memory phase must be free of VALU instructions: measured with s_memtime, a wave's VALU work (v_cndmask
+    // edge masks, 64-bit compares) does not issue while the other wave of the SIMD streams MFMAs, which stretched
+    // the memory phase from ~400 to ~4500 cycles.  Hence descriptor-enforced bounds and scalar-only address math.
+    if (grp == 1) __syncthreads();
 
     const int li = lane & 31, lh = lane >> 5;
     for (int tile = 0; tile < ntiles; ++tile) {
-        const int cur = tile & 1;
-        gload(kbeg + (tile + 1) * BK);   // past the last tile this reads zeros (kvalid <= 0), no branch needed
-        // keep the loads in flight UNDER the MFMAs: without this fence hipcc sinks them below the MFMA block and
-        // waits for them at once, exposing the whole HBM latency every K tile
-        __builtin_amdgcn_sched_barrier(0);
-        const float *as = As0 + cur * (BK * LDA) + wm * 64 + li;
-        const float *bs = Bs0 + cur * (BK * LDB) + wn * 64 + li;
+        const float *as = As + wm * WM_ + li;
+        const float *bs = Bs + wn * WN_ + li;
+        // fragments PF k-steps ahead of the MFMAs that consume them: the LDS latency, and the other group's burst of
+        // ds_writes in its memory phase, stay hidden behind 4*PF MFMAs (left alone hipcc reuses one register set and
+        // waits for every ds_read right before its MFMA group)
+        constexpr int PF = 2, KS = BK / 2;
+        float av[PF + 1][MI], bv[PF + 1][NJ];
 #pragma unroll
-        for (int kk = 0; kk < BK / 2; ++kk) {
-            const int k = 2 * kk + lh;
-            const float a0 = as[k * LDA], a1 = as[k * LDA + 32];
-            const float b0 = bs[k * LDB], b1 = bs[k * LDB + 32];
-            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+        for (int s0 = 0; s0 < PF; ++s0) {
+#pragma unroll
+            for (int i = 0; i < MI; ++i) av[s0][i] = as[(2 * s0 + lh) * LDA + 32 * i];
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) bv[s0][j] = bs[(2 * s0 + lh) * LDB + 32 * j];
+        }
+#pragma unroll
+        for (int kk = 0; kk < KS; ++kk) {
+            const int c = kk % (PF + 1), nx = (kk + PF) % (PF + 1);
+            if (kk + PF < KS) {
+                const int k = 2 * (kk + PF) + lh;
+#pragma unroll
+                for (int i = 0; i < MI; ++i) av[nx][i] = as[k * LDA + 32 * i];
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) bv[nx][j] = bs[k * LDB + 32 * j];
+            }
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int j = 0; j < NJ; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[c][i], bv[c][j], acc[i][j], 0, 0, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, MI + NJ, 0);   // the prefetch step's ds_reads first
+            __builtin_amdgcn_sched_group_barrier(0x008, MI * NJ, 0);   // then this step's MFMAs
         }
         __builtin_amdgcn_sched_barrier(0);
-        sstore(cur ^ 1, kbeg + (tile + 1) * BK);
-        __syncthreads();
+        __syncthreads();   // this group's tile is consumed; the other group starts computing
+        sstore(kbeg + (tile + 1) * BK);
+        __builtin_amdgcn_sched_barrier(0);   // all LDS writes before the new loads: their vmcnt waits stay exact
+        // the tile after that goes in flight now and lands during the two compute phases that follow (past the
+        // last tile it reads zeros: kvalid <= 0, no branch needed)
+        gload(kbeg + (tile + 2) * BK);
+        __syncthreads();   // the next tile is in place; the other group starts its memory phase
     }
+    if (grp == 0) __syncthreads();
 
     // epilogue: C/D map of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
     if (ATOMIC) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < MI; ++i)
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const int n = n0 + wn * 64 + j * 32 + li;
+            for (int j = 0; j < NJ; ++j) {
+                const int n = n0 + wn * WN_ + j * 32 + li;
 #pragma unroll
                 for (int e = 0; e < 16; ++e) {
-                    const int m = m0 + wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
-                    if (m < a.M && n < a.N) atomicAdd(C + (long)m * a.ldc + n, acc[i][j][e]);
+                    const int m = m0 + wm * WM_ + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+                    if (valid && m < a.M && n < a.N) atomicAdd(C + (long)m * a.ldc + n, acc[i][j][e]);
                 }
             }
     } else {
         const long o = (long)m0 * a.ldc + n0;
-        const __amdgpu_buffer_rsrc_t rc = make_rsrc(C + o, a.nC - o);
-        float bv[2][16];
+        const __amdgpu_buffer_rsrc_t rc = make_rsrc(C + o, nC - o);
+        float bias[MI][16];
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < MI; ++i)
 #pragma unroll
-            for (int e = 0; e < 16; ++e) bv[i][e] = 0.f;
+            for (int e = 0; e < 16; ++e) bias[i][e] = 0.f;
         if (a.bias) {
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+            for (int i = 0; i < MI; ++i)
 #pragma unroll
                 for (int e = 0; e < 16; ++e) {
-                    const int ml = wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
-                    bv[i][e] = a.bias[z1 * a.M + min(m0 + ml, a.M - 1)];
+                    const int ml = wm * WM_ + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+                    bias[i][e] = a.bias[z1 * a.M + min(m0 + ml, a.M - 1)];
                 }
         }
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < MI; ++i)
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const int nl = wn * 64 + j * 32 + li;
+            for (int j = 0; j < NJ; ++j) {
+                const int nl = wn * WN_ + j * 32 + li;
 #pragma unroll
                 for (int e = 0; e < 16; ++e) {
-                    const int ml = wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
-                    const float v = acc[i][j][e] + bv[i][e];
+                    const int ml = wm * WM_ + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+                    const float v = acc[i][j][e] + bias[i][e];
                     const bool ok = (m0 + ml < a.M) && (n0 + nl < a.N);
                     const unsigned voff = ok ? (unsigned)(((long)ml * a.ldc + nl) * 4) : OOB;
                     __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rc, voff, 0, 0);
@@ -253,12 +320,56 @@ __global__ __launch_bounds__(NT) void gemm_f32_mfma(GemmArgs a)
     }
 }
 
+// Flat grid: the wide tiles of all slices first, then the narrow tiles, so that the last (partial) round of
+// workgroups is made of quarter-size tiles spread over every CU instead of a few full tiles on a few CUs.
+// A workgroup is two wave groups with one tile each (adjacent in the logical order).  Inside a class the m tile is
+// fastest: the tiles that share a B tile run back to back on one XCD's L2.
+template <bool A_KC, bool B_KC, bool ATOMIC>
+__global__ __launch_bounds__(2 * NT) void gemm_f32_mfma(GemmArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int grp = __builtin_amdgcn_readfirstlane(threadIdx.x >> 8);
+    const int bid = blockIdx.x;
+    if (bid < a.blocks_big) {
+        int idx = 2 * xcd_order(bid, a.blocks_big) + grp;
+        const bool valid = idx < a.total_big;
+        idx = min(idx, a.total_big - 1);
+        const int per_z = a.tiles_m * a.nb;
+        const int z = idx / per_z, rem = idx - z * per_z;
+        const int tile_n = rem / a.tiles_m, tile_m = rem - tile_n * a.tiles_m;
+        gemm_tile<A_KC, B_KC, ATOMIC, BN>(a, smem, grp, valid, z, tile_m, tile_n * BN);
+    } else {
+        int idx = 2 * xcd_order(bid - a.blocks_big, a.blocks_nar) + grp;
+        const bool valid = idx < a.total_nar;
+        idx = min(idx, a.total_nar - 1);
+        const int per_z = a.tiles_m * a.nn;
+        const int z = idx / per_z, rem = idx - z * per_z;
+        const int tile_n = rem / a.tiles_m, tile_m = rem - tile_n * a.tiles_m;
+        gemm_tile<A_KC, B_KC, ATOMIC, BN_TAIL>(a, smem, grp, valid, z, tile_m, a.nb * BN + tile_n * BN_TAIL);
+    }
+}
+
+static int device_slots()
+{
+    // tiles in flight on the current device: one two-group workgroup per CU
+    static thread_local int cached_dev = -1, cached = 0;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return 512;
+    if (dev != cached_dev) {
+        int cus = 0;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+        cached = 2 * cus;
+        cached_dev = dev;
+    }
+    return cached;
+}
+
 template <bool A_KC, bool B_KC, bool ATOMIC>
 static int launch(GemmArgs &a, int nz0, hipStream_t stream, const char *what)
 {
-    constexpr int LDA = A_KC ? LD_KC : LD_MN;
-    constexpr int LDB = B_KC ? LD_KC : LD_MN;
-    const size_t smem = (size_t)(2 * BK * LDA + 2 * BK * LDB) * sizeof(float);
+    constexpr int LDA = LoaderSel<A_KC, BM>::type::LD;
+    constexpr int LDB = LoaderSel<B_KC, BN>::type::LD;
+    const size_t smem = (size_t)(2 * BK * LDA + 2 * BK * LDB) * sizeof(float);   // one A+B buffer per wave group
     // per-lane byte offsets are 32 bit and span one tile of rows: 128 rows * ld * 4 bytes must stay below 2^30
     if (a.lda >= (1L << 21) || a.ldb >= (1L << 21) || a.ldc >= (1L << 21))
         return fail(DDCN_ERR_UNSUPPORTED, "%s: leading dimension beyond 2^21 elements", what);
@@ -267,12 +378,25 @@ static int launch(GemmArgs &a, int nz0, hipStream_t stream, const char *what)
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     if (e != hipSuccess) return fail(DDCN_ERR_LAUNCH, "%s: hipFuncSetAttribute: %s", what, hipGetErrorString(e));
     a.tiles_m = (a.M + BM - 1) / BM;
-    a.tiles_n = (a.N + BN - 1) / BN;
-    const long tiles = (long)a.tiles_m * a.tiles_n;
-    dim3 grid((unsigned)tiles, 1, nz0 * a.nz1 * a.ksplit);
-    if (tiles == 0 || grid.z == 0) return DDCN_OK;
-    if (tiles > 0x7fffffffL || grid.z > 65535) return fail(DDCN_ERR_UNSUPPORTED, "%s: grid too large", what);
-    hipLaunchKernelGGL((gemm_f32_mfma<A_KC, B_KC, ATOMIC>), grid, dim3(NT), smem, stream, a);
+    const long tiles_n = (a.N + BN - 1) / BN;
+    const long nz = (long)nz0 * a.nz1 * a.ksplit;
+    if (a.tiles_m == 0 || tiles_n == 0 || nz == 0) return DDCN_OK;
+    // wide tiles for the whole rounds, narrow tiles for the remainder
+    const long slots = device_slots();
+    const long all_big = a.tiles_m * tiles_n * nz;
+    long nb = tiles_n;
+    static const int env_tail = getenv("DDCN_GEMM_TAIL") ? atoi(getenv("DDCN_GEMM_TAIL")) : 1;
+    if (env_tail && all_big > slots && all_big % slots != 0) nb = (all_big / slots) * slots / (a.tiles_m * nz);
+    if (nb > tiles_n) nb = tiles_n;
+    const long rest = (long)a.N - nb * BN;
+    const long nn = rest > 0 ? (rest + BN_TAIL - 1) / BN_TAIL : 0;
+    const long total_big = a.tiles_m * nb * nz, total_nar = a.tiles_m * nn * nz;
+    if (total_big + total_nar > 0x7fffffffL) return fail(DDCN_ERR_UNSUPPORTED, "%s: grid too large", what);
+    if (a.kchunk <= 0 || a.kchunk % BK) return fail(DDCN_ERR_BAD_ARG, "%s: reduction chunk not a multiple of %d", what, BK);
+    a.nb = (int)nb; a.nn = (int)nn; a.total_big = (int)total_big; a.total_nar = (int)total_nar;
+    a.blocks_big = (int)((total_big + 1) / 2); a.blocks_nar = (int)((total_nar + 1) / 2);
+    hipLaunchKernelGGL((gemm_f32_mfma<A_KC, B_KC, ATOMIC>), dim3((unsigned)(a.blocks_big + a.blocks_nar)), dim3(2 * NT),
+                       smem, stream, a);
     return check_launch(what);
 }
 
