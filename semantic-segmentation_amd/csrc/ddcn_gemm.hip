@@ -230,6 +230,7 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs &a, float *smem, int gr
 
     const int li = lane & 31, lh = lane >> 5;
     for (int tile = 0; tile < ntiles; ++tile) {
+        __builtin_amdgcn_s_setprio(2);   // the computing wave wins every issue arbitration against the other group's memory phase
         const float *as = As + wm * WM_ + li;
         const float *bs = Bs + wn * WN_ + li;
         // fragments PF k-steps ahead of the MFMAs that consume them: the LDS latency, and the other group's burst of
@@ -263,6 +264,7 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs &a, float *smem, int gr
             __builtin_amdgcn_sched_group_barrier(0x008, MI * NJ, 0);   // then this step's MFMAs
         }
         __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_setprio(0);
         __syncthreads();   // this group's tile is consumed; the other group starts computing
         sstore(kbeg + (tile + 1) * BK);
         __builtin_amdgcn_sched_barrier(0);   // all LDS writes before the new loads: their vmcnt waits stay exact

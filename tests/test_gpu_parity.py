@@ -140,8 +140,18 @@ def test_stage_im2col_and_scatter_against_oracle(c):
         assert cases.relerr(gmask[n].cpu().numpy(), egmask) <= BWD_TOL
 
 
-def test_stage_gemms_against_fp64_matmul():
-    c = cases.MEDIUM_CASES[2]   # Ci=128, Co=136 (M edge), P=625 (N edge), groups 1
+GEMM_CASES = [
+    cases.MEDIUM_CASES[2],   # Ci=128, Co=136 (M edge), P=625 (N edge), groups 1
+    # more column tiles than one round of workgroups: wide tiles + an ODD number of narrow tail tiles (one idle wave
+    # group), K = 36 and K = 72 (partial K tiles on both operand layouts), split-K over 66049 pixels
+    cases.C("gemm_tail_c4_257x257", N=1, Ci=4, Co=72, H=257, W=257, pad=1, dil=1, seed=60),
+    # 3 row tiles x 2 images: odd tile counts in the wide class
+    cases.C("gemm_odd_c8_150x150", N=2, Ci=8, Co=300, H=150, W=150, pad=1, dil=1, seed=61),
+]
+
+
+@pytest.mark.parametrize("c", GEMM_CASES, ids=lambda c: c["name"])
+def test_stage_gemms_against_fp64_matmul(c):
     g = _geom(c)
     L = _lib.lib()
     K2, P = 9, g.Ho * g.Wo
