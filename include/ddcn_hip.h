@@ -120,6 +120,19 @@ int ddcn_modulated_deform_conv_backward_f32(const float *x, const float *weight,
                                             const float *mask, const float *grad_out, float *gx, float *goff,
                                             float *gmask, float *gw, float *gb, void *workspace,
                                             size_t workspace_bytes, const ddcn_geom *g, void *stream);
+/* Backward variants that reuse the columns the forward call left in ITS workspace (`columns`, the [N][C*K2][ld]
+ * buffer of the matching forward call, unchanged since) instead of recomputing them: the reference's backward
+ * re-runs im2col per image (H:325-327 / H:524-527) because its `columns` tensor is overwritten in between.
+ * `workspace` is still needed for the column gradients.  columns == NULL behaves like the plain entry point. */
+int ddcn_deform_conv_backward_saved_f32(const float *x, const float *weight, const float *offset,
+                                        const float *grad_out, const float *columns, float *gx, float *goff,
+                                        float *gw, float *gb, void *workspace, size_t workspace_bytes,
+                                        const ddcn_geom *g, void *stream);
+int ddcn_modulated_deform_conv_backward_saved_f32(const float *x, const float *weight, const float *offset,
+                                                  const float *mask, const float *grad_out, const float *columns,
+                                                  float *gx, float *goff, float *gmask, float *gw, float *gb,
+                                                  void *workspace, size_t workspace_bytes, const ddcn_geom *g,
+                                                  void *stream);
 /* replaces depthaware_conv_cuda_forward (H:567-647) */
 int ddcn_depthaware_conv_forward_f32(const float *x, const float *depth, const float *weight, const float *bias,
                                      float *out, void *workspace, size_t workspace_bytes, const ddcn_geom *g,

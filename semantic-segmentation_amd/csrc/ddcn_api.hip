@@ -202,8 +202,8 @@ static int deform_forward(const float *x, const float *weight, const float *bias
 }
 
 static int deform_backward(const float *x, const float *weight, const float *offset, const float *mask,
-                           const float *gout, float *gx, float *goff, float *gmask, float *gw, float *gb, void *ws,
-                           size_t ws_bytes, const ddcn_geom *g, void *stream)
+                           const float *gout, const float *saved_cols, float *gx, float *goff, float *gmask,
+                           float *gw, float *gb, void *ws, size_t ws_bytes, const ddcn_geom *g, void *stream)
 {
     TRY(check_geom(g));
     TRY(check_ws(g, ws, ws_bytes));
@@ -211,8 +211,13 @@ static int deform_backward(const float *x, const float *weight, const float *off
     float *col = (float *)ws;
     TRY(launch_gemm_gcol(weight, gout, col, *g, s));
     TRY(launch_col2im_coord(col, x, offset, mask, gx, goff, gmask, *g, s));
-    TRY(launch_im2col(x, offset, mask, col, *g, s));
-    TRY(launch_gemm_gweight(gout, col, gw, *g, s));
+    if (saved_cols) {   // the forward call's columns are still there: no second im2col
+        if ((uintptr_t)saved_cols & 15) return fail(DDCN_ERR_BAD_ARG, "columns must be 16-byte aligned");
+        TRY(launch_gemm_gweight(gout, saved_cols, gw, *g, s));
+    } else {
+        TRY(launch_im2col(x, offset, mask, col, *g, s));
+        TRY(launch_gemm_gweight(gout, col, gw, *g, s));
+    }
     if (gb) TRY(launch_bias_grad(gout, gb, *g, s));
     return DDCN_OK;
 }
@@ -230,7 +235,17 @@ int ddcn_deform_conv_backward_f32(const float *x, const float *weight, const flo
                                   size_t workspace_bytes, const ddcn_geom *g, void *stream)
 {
     REQUIRE(x); REQUIRE(weight); REQUIRE(offset); REQUIRE(grad_out); REQUIRE(gx); REQUIRE(goff); REQUIRE(gw);
-    return deform_backward(x, weight, offset, nullptr, grad_out, gx, goff, nullptr, gw, gb, workspace,
+    return deform_backward(x, weight, offset, nullptr, grad_out, nullptr, gx, goff, nullptr, gw, gb, workspace,
+                           workspace_bytes, g, stream);
+}
+
+int ddcn_deform_conv_backward_saved_f32(const float *x, const float *weight, const float *offset,
+                                        const float *grad_out, const float *columns, float *gx, float *goff,
+                                        float *gw, float *gb, void *workspace, size_t workspace_bytes,
+                                        const ddcn_geom *g, void *stream)
+{
+    REQUIRE(x); REQUIRE(weight); REQUIRE(offset); REQUIRE(grad_out); REQUIRE(gx); REQUIRE(goff); REQUIRE(gw);
+    return deform_backward(x, weight, offset, nullptr, grad_out, columns, gx, goff, nullptr, gw, gb, workspace,
                            workspace_bytes, g, stream);
 }
 
@@ -249,8 +264,20 @@ int ddcn_modulated_deform_conv_backward_f32(const float *x, const float *weight,
 {
     REQUIRE(x); REQUIRE(weight); REQUIRE(offset); REQUIRE(mask); REQUIRE(grad_out);
     REQUIRE(gx); REQUIRE(goff); REQUIRE(gmask); REQUIRE(gw);
-    return deform_backward(x, weight, offset, mask, grad_out, gx, goff, gmask, gw, gb, workspace, workspace_bytes,
-                           g, stream);
+    return deform_backward(x, weight, offset, mask, grad_out, nullptr, gx, goff, gmask, gw, gb, workspace,
+                           workspace_bytes, g, stream);
+}
+
+int ddcn_modulated_deform_conv_backward_saved_f32(const float *x, const float *weight, const float *offset,
+                                                  const float *mask, const float *grad_out, const float *columns,
+                                                  float *gx, float *goff, float *gmask, float *gw, float *gb,
+                                                  void *workspace, size_t workspace_bytes, const ddcn_geom *g,
+                                                  void *stream)
+{
+    REQUIRE(x); REQUIRE(weight); REQUIRE(offset); REQUIRE(mask); REQUIRE(grad_out);
+    REQUIRE(gx); REQUIRE(goff); REQUIRE(gmask); REQUIRE(gw);
+    return deform_backward(x, weight, offset, mask, grad_out, columns, gx, goff, gmask, gw, gb, workspace,
+                           workspace_bytes, g, stream);
 }
 
 int ddcn_depthaware_conv_forward_f32(const float *x, const float *depth, const float *weight, const float *bias,

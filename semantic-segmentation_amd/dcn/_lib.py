@@ -45,6 +45,8 @@ PROTOTYPES = {
     "ddcn_deform_conv_backward_f32": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _SZ, _G, _P],
     "ddcn_modulated_deform_conv_forward_f32": [_P, _P, _P, _P, _P, _P, _P, _SZ, _G, _P],
     "ddcn_modulated_deform_conv_backward_f32": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _SZ, _G, _P],
+    "ddcn_deform_conv_backward_saved_f32": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _SZ, _G, _P],
+    "ddcn_modulated_deform_conv_backward_saved_f32": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _SZ, _G, _P],
     "ddcn_depthaware_conv_forward_f32": [_P, _P, _P, _P, _P, _P, _SZ, _G, _P],
     "ddcn_depthaware_conv_backward_f32": [_P, _P, _P, _P, _P, _P, _P, _P, _SZ, _G, _P],
 }

@@ -16,6 +16,8 @@ Deliberate deviations from the reference:
 """
 import math
 
+import os
+
 import torch
 import torch.nn as nn
 from torch.autograd import Function
@@ -52,6 +54,11 @@ def _contig(name, t):
     # deform_conv_cuda.cpp:179-180: input and weight must be contiguous
     if not t.is_contiguous():
         raise RuntimeError("%s tensor has to be contiguous" % name)
+
+
+# Keep the forward call's columns for backward (no second im2col) at the price of holding N*C*K2*ld floats per layer
+# between forward and backward; DDCN_SAVE_COLUMNS=0 restores the reference's recompute (deform_conv_cuda.cpp:325-327).
+SAVE_COLUMNS = os.environ.get("DDCN_SAVE_COLUMNS", "1") != "0"
 
 
 def _workspace(input, g):
@@ -103,8 +110,8 @@ class DeformConvFunction(Function):
         k2 = g.kh * g.kw
         _expect_shape("offset", offset, (g.N, deformable_groups * 2 * k2, g.Ho, g.Wo))
         offset = offset.contiguous()
-        if weight.requires_grad or offset.requires_grad \
-                or input.requires_grad:
+        needs_grad = weight.requires_grad or offset.requires_grad or input.requires_grad
+        if needs_grad:
             ctx.save_for_backward(input, offset, weight, bias)
         output = input.new_empty(
             DeformConvFunction._infer_shape(ctx, input, weight))
@@ -113,6 +120,7 @@ class DeformConvFunction(Function):
             _lib.check(_lib.lib().ddcn_deform_conv_forward_f32(
                 _lib.ptr(input), _lib.ptr(weight), _lib.ptr(bias) if ctx.with_bias else None, _lib.ptr(offset),
                 _lib.ptr(output), _lib.ptr(ws), ws_bytes, g, _lib.current_stream(input.device)))
+        ctx.columns = ws if (needs_grad and SAVE_COLUMNS) else None
         return output
 
     @staticmethod
@@ -130,8 +138,10 @@ class DeformConvFunction(Function):
         _expect_shape("grad_output", grad_output, (g.N, g.Co, g.Ho, g.Wo))
         ws, ws_bytes = _workspace(input, g)
         with torch.cuda.device(input.device):
-            _lib.check(_lib.lib().ddcn_deform_conv_backward_f32(
-                _lib.ptr(input), _lib.ptr(weight), _lib.ptr(offset), _lib.ptr(grad_output), _lib.ptr(grad_input),
+            cols, ctx.columns = getattr(ctx, "columns", None), None
+            _lib.check(_lib.lib().ddcn_deform_conv_backward_saved_f32(
+                _lib.ptr(input), _lib.ptr(weight), _lib.ptr(offset), _lib.ptr(grad_output),
+                _lib.ptr(cols) if cols is not None else None, _lib.ptr(grad_input),
                 _lib.ptr(grad_offset), _lib.ptr(grad_weight), _lib.ptr(grad_bias) if ctx.with_bias else None,
                 _lib.ptr(ws), ws_bytes, g, _lib.current_stream(input.device)))
         if not ctx.with_bias:
@@ -177,8 +187,8 @@ class ModulatedDeformConvFunction(Function):
         _expect_shape("mask", mask, (g.N, deformable_groups * k2, g.Ho, g.Wo))
         offset = offset.contiguous()
         mask = mask.contiguous()
-        if weight.requires_grad or mask.requires_grad or offset.requires_grad \
-                or input.requires_grad:
+        needs_grad = weight.requires_grad or mask.requires_grad or offset.requires_grad or input.requires_grad
+        if needs_grad:
             ctx.save_for_backward(input, offset, mask, weight, bias)
         output = input.new_empty(
             ModulatedDeformConvFunction._infer_shape(ctx, input, weight))
@@ -187,6 +197,7 @@ class ModulatedDeformConvFunction(Function):
             _lib.check(_lib.lib().ddcn_modulated_deform_conv_forward_f32(
                 _lib.ptr(input), _lib.ptr(weight), _lib.ptr(bias) if ctx.with_bias else None, _lib.ptr(offset),
                 _lib.ptr(mask), _lib.ptr(output), _lib.ptr(ws), ws_bytes, g, _lib.current_stream(input.device)))
+        ctx.columns = ws if (needs_grad and SAVE_COLUMNS) else None
         return output
 
     @staticmethod
@@ -205,9 +216,10 @@ class ModulatedDeformConvFunction(Function):
         _expect_shape("grad_output", grad_output, (g.N, g.Co, g.Ho, g.Wo))
         ws, ws_bytes = _workspace(input, g)
         with torch.cuda.device(input.device):
-            _lib.check(_lib.lib().ddcn_modulated_deform_conv_backward_f32(
+            cols, ctx.columns = getattr(ctx, "columns", None), None
+            _lib.check(_lib.lib().ddcn_modulated_deform_conv_backward_saved_f32(
                 _lib.ptr(input), _lib.ptr(weight), _lib.ptr(offset), _lib.ptr(mask), _lib.ptr(grad_output),
-                _lib.ptr(grad_input), _lib.ptr(grad_offset), _lib.ptr(grad_mask), _lib.ptr(grad_weight),
+                _lib.ptr(cols) if cols is not None else None, _lib.ptr(grad_input), _lib.ptr(grad_offset), _lib.ptr(grad_mask), _lib.ptr(grad_weight),
                 _lib.ptr(grad_bias) if ctx.with_bias else None, _lib.ptr(ws), ws_bytes, g,
                 _lib.current_stream(input.device)))
         if not ctx.with_bias:

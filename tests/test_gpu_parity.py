@@ -183,6 +183,28 @@ def test_stage_gemms_against_fp64_matmul(c):
     assert cases.relerr(gb.cpu().numpy(), 1.0 + gout.astype(np.float64).sum(axis=(0, 2))) <= BWD_TOL
 
 
+@pytest.mark.parametrize("c", [cases.MEDIUM_CASES[0], cases.MEDIUM_CASES[1]], ids=lambda c: c["name"])
+def test_backward_recompute_path_matches_saved_columns_path(c, monkeypatch):
+    """The Python layer keeps the forward columns by default (ddcn_*_backward_saved_f32); with SAVE_COLUMNS off it
+    calls the plain entry points, which re-run im2col like the reference (deform_conv_cuda.cpp:325-327).  Both must
+    meet the oracle bar."""
+    mod = importlib.import_module("semantic-segmentation_amd.dcn.deform_conv")
+    inp = _r32(cases.make_inputs(c))
+    kw = cases.kwargs(c)
+    exp = dict(out=orc.deform_forward(inp["x"], inp["offset"], inp["mask"], inp["weight"], inp["bias"], **kw))
+    exp["gx"], exp["goff"], exp["gmask"], exp["gw"], exp["gb"] = orc.deform_backward(
+        inp["x"], inp["offset"], inp["mask"], inp["weight"], inp["gout"], c["bias"], **kw)
+    res = {}
+    for flag in (True, False):
+        monkeypatch.setattr(mod, "SAVE_COLUMNS", flag)
+        res[flag] = _run_hip(c, inp)
+    for k, v in res[True][1].items():
+        if v is not None:
+            assert cases.relerr(res[False][1][k], v.astype(np.float64)) <= BWD_TOL, k
+    assert np.array_equal(res[True][0], res[False][0])
+    _assert_case(c, res[False][0], res[False][1], exp)
+
+
 # ---------------------------------------------------------------- the reference's own self-tests, on the GPU
 def test_ref_selftest_zero_offset_equals_conv2d_gpu():
     # detseg/ops/dcn/test.py:17-94 (a),(b)
