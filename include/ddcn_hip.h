@@ -100,8 +100,8 @@ int ddcn_bias_grad_f32(const float *grad_out, float *gb, const ddcn_geom *g, voi
  * One per function of the reference's pybind module (H:758-775).  The reference's `ones` and
  * `columns` tensor arguments are replaced by (workspace, workspace_bytes); `with_bias` by a NULL
  * bias / gb pointer; the eight kernel/stride/pad/dilation ints, group and deformable_group by geom.
- * Backward ACCUMULATES into gx, gw, gb (the reference's Python pre-zeroes them, PY:54-57, PY:126-130)
- * and OVERWRITES goff / gmask. */
+ * Backward ACCUMULATES into gx, goff, gmask, gw, gb: zero-fill them first, as the reference's Python does for
+ * all five (PY:54-57, PY:126-130) -- one fill of one flat buffer in semantic-segmentation_amd/dcn/deform_conv.py. */
 
 /* replaces deform_conv_cuda_forward (H:173-251) */
 int ddcn_deform_conv_forward_f32(const float *x, const float *weight, const float *bias, const float *offset,

@@ -210,7 +210,7 @@ static int deform_backward(const float *x, const float *weight, const float *off
     hipStream_t s = (hipStream_t)stream;
     float *col = (float *)ws;
     TRY(launch_gemm_gcol(weight, gout, col, *g, s));
-    TRY(launch_col2im_coord(col, x, offset, mask, gx, goff, gmask, *g, s));
+    TRY(launch_col2im_coord(col, x, offset, mask, gx, goff, gmask, *g, s, /*clear_coord=*/false));
     if (saved_cols) {   // the forward call's columns are still there: no second im2col
         if ((uintptr_t)saved_cols & 15) return fail(DDCN_ERR_BAD_ARG, "columns must be 16-byte aligned");
         TRY(launch_gemm_gweight(gout, saved_cols, gw, *g, s));

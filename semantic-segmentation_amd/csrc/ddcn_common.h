@@ -39,7 +39,7 @@ int launch_im2col(const float *x, const float *offset, const float *mask, float 
 int launch_im2col_tiled(const float *x, const float *offset, const float *mask, float *col, const ddcn_geom &g,
                         hipStream_t stream, bool *handled);
 int launch_col2im_coord(const float *gcol, const float *x, const float *offset, const float *mask, float *gx,
-                        float *goff, float *gmask, const ddcn_geom &g, hipStream_t stream);
+                        float *goff, float *gmask, const ddcn_geom &g, hipStream_t stream, bool clear_coord = true);
 int launch_col2im_coord_tile9(const float *gcol, const float *x, const float *offset, const float *mask, float *gx,
                               float *goff, float *gmask, const ddcn_geom &g, hipStream_t stream, bool *handled);
 int launch_col2im_coord_tiled(const float *gcol, const float *x, const float *offset, const float *mask, float *gx,

@@ -298,13 +298,16 @@ int launch_im2col(const float *x, const float *offset, const float *mask, float 
 }
 
 int launch_col2im_coord(const float *gcol, const float *x, const float *offset, const float *mask, float *gx,
-                        float *goff, float *gmask, const ddcn_geom &g, hipStream_t stream)
+                        float *goff, float *gmask, const ddcn_geom &g, hipStream_t stream, bool clear_coord)
 {
     GatherArgs a = base_args(g);
     a.gcol = gcol; a.x = x; a.offset = offset; a.mask = mask; a.gx = gx; a.goff = goff; a.gmask = gmask;
     // goff / gmask are sums over channel chunks: clear, then accumulate (plain-store semantics of K:433, K:761-764)
-    hipError_t e = hipMemsetAsync(goff, 0, sizeof(float) * (size_t)g.N * g.dg * 2 * a.K2 * a.P, stream);
-    if (e == hipSuccess && gmask) e = hipMemsetAsync(gmask, 0, sizeof(float) * (size_t)g.N * g.dg * a.K2 * a.P, stream);
+    // (the whole-op backward entry points leave the clearing to the caller, who zero-fills every gradient anyway)
+    hipError_t e = hipSuccess;
+    if (clear_coord) e = hipMemsetAsync(goff, 0, sizeof(float) * (size_t)g.N * g.dg * 2 * a.K2 * a.P, stream);
+    if (clear_coord && e == hipSuccess && gmask)
+        e = hipMemsetAsync(gmask, 0, sizeof(float) * (size_t)g.N * g.dg * a.K2 * a.P, stream);
     if (e != hipSuccess) return fail(DDCN_ERR_LAUNCH, "col2im_coord: memset: %s", hipGetErrorString(e));
     bool handled = false;
     int rc = launch_col2im_coord_tile9(gcol, x, offset, mask, gx, goff, gmask, g, stream, &handled);

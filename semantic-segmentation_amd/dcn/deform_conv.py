@@ -66,6 +66,17 @@ def _workspace(input, g):
     return torch.empty(nbytes // 4, dtype=torch.float32, device=input.device), nbytes
 
 
+def _zeros_like_all(*tensors):
+    """Zero-filled gradients for all tensors from ONE flat buffer and one fill kernel (each view 16-byte aligned)."""
+    sizes = [(t.numel() + 3) // 4 * 4 for t in tensors]
+    flat = torch.zeros(sum(sizes), dtype=tensors[0].dtype, device=tensors[0].device)
+    out, o = [], 0
+    for t, n in zip(tensors, sizes):
+        out.append(flat[o:o + t.numel()].view(t.shape))
+        o += n
+    return out
+
+
 def _expect_shape(name, t, shape):
     if tuple(t.shape) != tuple(shape):
         raise RuntimeError("invalid shape of %s, expected %s but got %s" % (name, tuple(shape), tuple(t.shape)))
@@ -130,10 +141,7 @@ class DeformConvFunction(Function):
             raise NotImplementedError
         input, offset, weight, bias = ctx.saved_tensors
         grad_output = grad_output.contiguous()
-        grad_input = torch.zeros_like(input)
-        grad_offset = torch.zeros_like(offset)
-        grad_weight = torch.zeros_like(weight)
-        grad_bias = torch.zeros_like(bias)
+        grad_input, grad_offset, grad_weight, grad_bias = _zeros_like_all(input, offset, weight, bias)
         g = _geom(input, weight, ctx.stride, ctx.padding, ctx.dilation, ctx.groups, ctx.deformable_groups)
         _expect_shape("grad_output", grad_output, (g.N, g.Co, g.Ho, g.Wo))
         ws, ws_bytes = _workspace(input, g)
@@ -207,11 +215,7 @@ class ModulatedDeformConvFunction(Function):
             raise NotImplementedError
         input, offset, mask, weight, bias = ctx.saved_tensors
         grad_output = grad_output.contiguous()
-        grad_input = torch.zeros_like(input)
-        grad_offset = torch.zeros_like(offset)
-        grad_mask = torch.zeros_like(mask)
-        grad_weight = torch.zeros_like(weight)
-        grad_bias = torch.zeros_like(bias)
+        grad_input, grad_offset, grad_mask, grad_weight, grad_bias = _zeros_like_all(input, offset, mask, weight, bias)
         g = _geom(input, weight, ctx.stride, ctx.padding, ctx.dilation, ctx.groups, ctx.deformable_groups)
         _expect_shape("grad_output", grad_output, (g.N, g.Co, g.Ho, g.Wo))
         ws, ws_bytes = _workspace(input, g)
