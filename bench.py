@@ -103,6 +103,13 @@ def kernel_rooflines(w, tensors, iters):
         ("gemm_gweight", "mfma", a["f_gemm"] * N,
          lambda: _lib.check(L.ddcn_gemm_gweight_f32(p(gout), p(col), p(gw), g, s))),
     ]
+    # HBM bytes per launch from the PMC passes committed under profiles/ (rocprofv3 cannot run inside this process);
+    # they belong to the default workload only
+    traffic = {}
+    tf = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01e_hbm_traffic.json")
+    if os.path.exists(tf) and (w["N"], w["C"], w["Co"], w["H"], w["W"], w["dil"]) == (2, 512, 512, 97, 97, 4):
+        with open(tf) as fh:
+            traffic = {k: v["traffic_bytes"] for k, v in json.load(fh)["kernels"].items()}
     res = []
     for name, bound, work, fn in stages:
         ms = time_stage(fn, iters)
@@ -111,7 +118,7 @@ def kernel_rooflines(w, tensors, iters):
         else:
             ach, peak, unit = work / ms / 1e9, MFMA_F32_PEAK_TF, "TFLOP/s"
         res.append(dict(kernel=name, bound=bound, ms=round(ms, 4), achieved=round(ach, 2), peak=peak, unit=unit,
-                        frac=round(ach / peak, 4), traffic=None))
+                        frac=round(ach / peak, 4), traffic=traffic.get(name)))
     return res
 
 
