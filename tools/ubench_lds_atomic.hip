@@ -30,6 +30,8 @@ __global__ __launch_bounds__(256) void k(float *out, int iters, int region, int 
             } while (old != assumed);
         }
         if (MODE == 6) atomicAdd((double *)&s[idx & ~1], (double)v);            // ds_add_f64
+        if (MODE == 8) atomicAdd((double *)&s[((threadIdx.x + it * 3) * 2) % (region - 2)], (double)v);   // ds_add_f64, lanes on consecutive doubles
+        if (MODE == 9) atomicAdd((unsigned *)&s[(threadIdx.x + it * 3) % region], (unsigned)(st & 255));      // ds_add_u32, consecutive
         if (MODE == 7) {                                                        // 4 CAS loops interleaved (4 corners)
             unsigned *a0 = (unsigned *)&s[idx], *a1 = a0 + 1, *a2 = a0 + 46, *a3 = a0 + 47;
             unsigned o0 = *a0, o1 = *a1, o2 = *a2, o3 = *a3;
@@ -77,6 +79,8 @@ int main()
     for (int spread : {64, 1024}) {
         run<0>("ds_add_f32", 2000, 11408, spread);
         run<1>("read+write", 2000, 11408, spread);
+        run<8>("ds_add_f64 linear", 2000, 11408, spread);
+        run<9>("ds_add_u32 linear", 2000, 11408, spread);
         run<2>("ds_add_u32", 2000, 11408, spread);
         run<3>("ds_read", 2000, 11408, spread);
         run<4>("ds_add_rtn_f32", 2000, 11408, spread);
