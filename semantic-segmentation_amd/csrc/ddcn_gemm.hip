@@ -389,6 +389,9 @@ static int launch(GemmArgs &a, int nz0, hipStream_t stream, const char *what)
     long nb = tiles_n;
     static const int env_tail = getenv("DDCN_GEMM_TAIL") ? atoi(getenv("DDCN_GEMM_TAIL")) : 1;
     if (env_tail && all_big > slots && all_big % slots != 0) nb = (all_big / slots) * slots / (a.tiles_m * nz);
+    // less than one round of wide tiles (skinny problems such as the 9-row mask convolution of the DDCN layer): the
+    // launch lasts as long as ONE tile's K loop, and a narrow tile's loop is ~3x shorter
+    if (env_tail && all_big < slots && !ATOMIC) nb = 0;
     if (nb > tiles_n) nb = tiles_n;
     const long rest = (long)a.N - nb * BN;
     const long nn = rest > 0 ? (rest + BN_TAIL - 1) / BN_TAIL : 0;
