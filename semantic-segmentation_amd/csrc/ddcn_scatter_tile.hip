@@ -33,7 +33,6 @@ struct TileArgs {
     int CG, CC, M;
     int RH, RW, RS;
     int stepR, stepC;  // TT / RW, TT % RW
-    int ablate;
 };
 
 template <bool MOD>
@@ -102,13 +101,11 @@ __global__ __launch_bounds__(TT) void col2im_coord_tile_kernel(TileArgs a)
 #pragma unroll 4
                 for (int cc = 0; cc < a.CC; ++cc) {
                     const float *im = xb + cc * HW + gi;
-                    const float gc = (a.ablate & 8) ? h : gck[(long)cc * K2 * a.ld];
-                    float v1, v2, v3, v4;
-                    if (a.ablate & 4) { v1 = v2 = v3 = v4 = gc; } else {
-                    v1 = ok1 ? im[0] : 0.f;
-                    v2 = ok2 ? im[1] : 0.f;
-                    v3 = ok3 ? im[g.W] : 0.f;
-                    v4 = ok4 ? im[g.W + 1] : 0.f; }
+                    const float gc = gck[(long)cc * K2 * a.ld];
+                    const float v1 = ok1 ? im[0] : 0.f;
+                    const float v2 = ok2 ? im[1] : 0.f;
+                    const float v3 = ok3 ? im[g.W] : 0.f;
+                    const float v4 = ok4 ? im[g.W + 1] : 0.f;
                     float wh = 0.f, ww = 0.f;
                     wh += -1.f * cwl * v1; wh += -1.f * cwh * v2; wh += cwl * v3; wh += cwh * v4;
                     ww += -1.f * chl * v1; ww += chl * v2; ww += -1.f * chh * v3; ww += chh * v4;
@@ -123,7 +120,6 @@ __global__ __launch_bounds__(TT) void col2im_coord_tile_kernel(TileArgs a)
                         aw += ww * gc;
                         tg = gc;
                     }
-                    if (a.ablate & 1) { am += tg * s1 + s2 + s3 + s4; } else
                     if (inreg) {
                         double *cell = gs + cc * a.RS + ri;
                         if (ok1) atomicAdd(cell, (double)(s1 * tg));
@@ -146,7 +142,6 @@ __global__ __launch_bounds__(TT) void col2im_coord_tile_kernel(TileArgs a)
         }
         __syncthreads();
         // flush the footprint: one global atomic per touched in-image cell, and re-zero for the next chunk
-        if (!(a.ablate & 2))
         for (int cc = 0; cc < a.CC; ++cc) {
             double *gsc = gs + cc * a.RS;
             float *gxc = gxb + cc * HW;
@@ -237,7 +232,6 @@ int launch_col2im_coord_tiled(const float *gcol, const float *x, const float *of
     *handled = true;
     const Dims d = dims_of(g);
     a.gcol = gcol; a.x = x; a.offset = offset; a.mask = mask; a.gx = gx; a.goff = goff; a.gmask = gmask;
-    a.ablate = getenv("DDCN_ABLATE") ? atoi(getenv("DDCN_ABLATE")) : 0;
     a.g = g; a.P = d.P; a.cpg = d.cpg; a.ld = d.ld;
     dim3 grid(a.tiles_w * ((g.Ho + a.TH - 1) / a.TH), g.C / a.CG, g.N);
     if (grid.y > 65535 || grid.z > 65535) return fail(DDCN_ERR_UNSUPPORTED, "col2im_coord_tile: grid too large");

@@ -43,11 +43,24 @@ def _geom(input, weight, stride, padding, dilation, groups, deformable_groups):
     return g
 
 
-def _check_f32_cuda(name, t):
+_DTYPES = (torch.float32, torch.float16, torch.bfloat16)
+
+
+def _check_dtype_cuda(name, t, dtype):
+    """The reference dispatches on FLOATING_TYPES_AND_HALF (deform_conv_cuda_kernel.cu:258).  Here the kernels are
+    fp32: half / bfloat16 tensors are accepted and computed in fp32 (converted on the way in and out, so the result
+    is at least as accurate as a native half kernel); float64 is refused."""
     if not t.is_cuda:
         raise NotImplementedError
-    if t.dtype != torch.float32:
-        raise RuntimeError("ddcn: %s must be float32 (got %s); fp32 is the only dtype built so far" % (name, t.dtype))
+    if dtype not in _DTYPES:
+        raise RuntimeError("ddcn: %s dtype not supported (float32, float16, bfloat16)" % (dtype,))
+    if t.dtype != dtype:
+        raise RuntimeError("ddcn: %s is %s but input is %s; all tensors of one call must share a dtype"
+                           % (name, t.dtype, dtype))
+
+
+def _f32(t):
+    return t if t.dtype == torch.float32 else t.float()
 
 
 def _contig(name, t):
@@ -114,7 +127,8 @@ class DeformConvFunction(Function):
         if not input.is_cuda:
             raise NotImplementedError
         for name, t in (("input", input), ("offset", offset), ("weight", weight), ("bias", bias)):
-            _check_f32_cuda(name, t)
+            _check_dtype_cuda(name, t, input.dtype)
+        ctx.dtype = input.dtype
         _contig("input", input)
         _contig("weight", weight)
         g = _geom(input, weight, stride, padding, dilation, groups, deformable_groups)
@@ -124,6 +138,7 @@ class DeformConvFunction(Function):
         needs_grad = weight.requires_grad or offset.requires_grad or input.requires_grad
         if needs_grad:
             ctx.save_for_backward(input, offset, weight, bias)
+        input, offset, weight, bias = (_f32(t) for t in (input, offset, weight, bias))
         output = input.new_empty(
             DeformConvFunction._infer_shape(ctx, input, weight))
         ws, ws_bytes = _workspace(input, g)
@@ -132,15 +147,15 @@ class DeformConvFunction(Function):
                 _lib.ptr(input), _lib.ptr(weight), _lib.ptr(bias) if ctx.with_bias else None, _lib.ptr(offset),
                 _lib.ptr(output), _lib.ptr(ws), ws_bytes, g, _lib.current_stream(input.device)))
         ctx.columns = ws if (needs_grad and SAVE_COLUMNS) else None
-        return output
+        return output if ctx.dtype == torch.float32 else output.to(ctx.dtype)
 
     @staticmethod
     @once_differentiable
     def backward(ctx, grad_output):
         if not grad_output.is_cuda:
             raise NotImplementedError
-        input, offset, weight, bias = ctx.saved_tensors
-        grad_output = grad_output.contiguous()
+        input, offset, weight, bias = (_f32(t) for t in ctx.saved_tensors)
+        grad_output = _f32(grad_output.contiguous())
         grad_input, grad_offset, grad_weight, grad_bias = _zeros_like_all(input, offset, weight, bias)
         g = _geom(input, weight, ctx.stride, ctx.padding, ctx.dilation, ctx.groups, ctx.deformable_groups)
         _expect_shape("grad_output", grad_output, (g.N, g.Co, g.Ho, g.Wo))
@@ -154,6 +169,9 @@ class DeformConvFunction(Function):
                 _lib.ptr(ws), ws_bytes, g, _lib.current_stream(input.device)))
         if not ctx.with_bias:
             grad_bias = None
+        if ctx.dtype != torch.float32:
+            grad_input, grad_offset, grad_weight, grad_bias = (
+                None if t is None else t.to(ctx.dtype) for t in (grad_input, grad_offset, grad_weight, grad_bias))
 
         return (grad_input, grad_offset, grad_weight, grad_bias,
                 None, None, None, None, None)
@@ -186,7 +204,8 @@ class ModulatedDeformConvFunction(Function):
         if not input.is_cuda:
             raise NotImplementedError
         for name, t in (("input", input), ("offset", offset), ("mask", mask), ("weight", weight), ("bias", bias)):
-            _check_f32_cuda(name, t)
+            _check_dtype_cuda(name, t, input.dtype)
+        ctx.dtype = input.dtype
         _contig("input", input)
         _contig("weight", weight)
         g = _geom(input, weight, stride, padding, dilation, groups, deformable_groups)
@@ -198,6 +217,7 @@ class ModulatedDeformConvFunction(Function):
         needs_grad = weight.requires_grad or mask.requires_grad or offset.requires_grad or input.requires_grad
         if needs_grad:
             ctx.save_for_backward(input, offset, mask, weight, bias)
+        input, offset, mask, weight, bias = (_f32(t) for t in (input, offset, mask, weight, bias))
         output = input.new_empty(
             ModulatedDeformConvFunction._infer_shape(ctx, input, weight))
         ws, ws_bytes = _workspace(input, g)
@@ -206,15 +226,15 @@ class ModulatedDeformConvFunction(Function):
                 _lib.ptr(input), _lib.ptr(weight), _lib.ptr(bias) if ctx.with_bias else None, _lib.ptr(offset),
                 _lib.ptr(mask), _lib.ptr(output), _lib.ptr(ws), ws_bytes, g, _lib.current_stream(input.device)))
         ctx.columns = ws if (needs_grad and SAVE_COLUMNS) else None
-        return output
+        return output if ctx.dtype == torch.float32 else output.to(ctx.dtype)
 
     @staticmethod
     @once_differentiable
     def backward(ctx, grad_output):
         if not grad_output.is_cuda:
             raise NotImplementedError
-        input, offset, mask, weight, bias = ctx.saved_tensors
-        grad_output = grad_output.contiguous()
+        input, offset, mask, weight, bias = (_f32(t) for t in ctx.saved_tensors)
+        grad_output = _f32(grad_output.contiguous())
         grad_input, grad_offset, grad_mask, grad_weight, grad_bias = _zeros_like_all(input, offset, mask, weight, bias)
         g = _geom(input, weight, ctx.stride, ctx.padding, ctx.dilation, ctx.groups, ctx.deformable_groups)
         _expect_shape("grad_output", grad_output, (g.N, g.Co, g.Ho, g.Wo))
@@ -228,6 +248,10 @@ class ModulatedDeformConvFunction(Function):
                 _lib.current_stream(input.device)))
         if not ctx.with_bias:
             grad_bias = None
+        if ctx.dtype != torch.float32:
+            grad_input, grad_offset, grad_mask, grad_weight, grad_bias = (
+                None if t is None else t.to(ctx.dtype)
+                for t in (grad_input, grad_offset, grad_mask, grad_weight, grad_bias))
 
         return (grad_input, grad_offset, grad_mask, grad_weight, grad_bias,
                 None, None, None, None, None)
@@ -257,7 +281,8 @@ class DepthawareConvFunction(Function):
         if not input.is_cuda:
             raise NotImplementedError
         for name, t in (("input", input), ("depth", depth), ("weight", weight), ("bias", bias)):
-            _check_f32_cuda(name, t)
+            _check_dtype_cuda(name, t, input.dtype)
+        ctx.dtype = input.dtype
         _contig("input", input)
         _contig("weight", weight)
         g = _geom(input, weight, stride, padding, dilation, groups, 1)
@@ -265,6 +290,7 @@ class DepthawareConvFunction(Function):
         depth = depth.contiguous()
         if weight.requires_grad or input.requires_grad:
             ctx.save_for_backward(input, depth, weight, bias)
+        input, depth, weight, bias = (_f32(t) for t in (input, depth, weight, bias))
         output = input.new_empty(
             DepthawareConvFunction._infer_shape(ctx, input, weight))
         ws, ws_bytes = _workspace(input, g)
@@ -272,15 +298,15 @@ class DepthawareConvFunction(Function):
             _lib.check(_lib.lib().ddcn_depthaware_conv_forward_f32(
                 _lib.ptr(input), _lib.ptr(depth), _lib.ptr(weight), _lib.ptr(bias) if ctx.with_bias else None,
                 _lib.ptr(output), _lib.ptr(ws), ws_bytes, g, _lib.current_stream(input.device)))
-        return output
+        return output if ctx.dtype == torch.float32 else output.to(ctx.dtype)
 
     @staticmethod
     @once_differentiable
     def backward(ctx, grad_output):
         if not grad_output.is_cuda:
             raise NotImplementedError
-        input, depth, weight, bias = ctx.saved_tensors
-        grad_output = grad_output.contiguous()
+        input, depth, weight, bias = (_f32(t) for t in ctx.saved_tensors)
+        grad_output = _f32(grad_output.contiguous())
         grad_input = torch.zeros_like(input)
         grad_weight = torch.zeros_like(weight)
         grad_bias = torch.zeros_like(bias)
@@ -294,6 +320,9 @@ class DepthawareConvFunction(Function):
                 _lib.current_stream(input.device)))
         if not ctx.with_bias:
             grad_bias = None
+        if ctx.dtype != torch.float32:
+            grad_input, grad_weight, grad_bias = (
+                None if t is None else t.to(ctx.dtype) for t in (grad_input, grad_weight, grad_bias))
 
         # one gradient slot per forward input (the reference returned a surplus trailing None, PY:207-208)
         return (grad_input, None, grad_weight, grad_bias,

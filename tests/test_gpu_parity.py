@@ -205,6 +205,34 @@ def test_backward_recompute_path_matches_saved_columns_path(c, monkeypatch):
     _assert_case(c, res[False][0], res[False][1], exp)
 
 
+@pytest.mark.parametrize("dtype,tol", [(torch.float16, 2e-3), (torch.bfloat16, 1.5e-2)], ids=["f16", "bf16"])
+def test_half_and_bfloat16_tensors_are_computed_in_fp32(dtype, tol):
+    """The reference dispatches FLOATING_TYPES_AND_HALF (deform_conv_cuda_kernel.cu:258); here low-precision tensors
+    are converted, computed by the fp32 kernels and converted back.  Expected value: the fp64 oracle on the SAME
+    low-precision-rounded inputs; the tolerance is the output rounding of the dtype (parity unpinned by the
+    reference, which has no half-precision test)."""
+    c = cases.MEDIUM_CASES[0]
+    inp = cases.make_inputs(c)
+    rnd = {k: (None if v is None else torch.from_numpy(v).to(dtype).to(torch.float64).numpy()) for k, v in inp.items()}
+    kw = cases.kwargs(c)
+    eout = orc.deform_forward(rnd["x"], rnd["offset"], rnd["mask"], rnd["weight"], rnd["bias"], **kw)
+    egx, egoff, egmask, egw, _ = orc.deform_backward(rnd["x"], rnd["offset"], rnd["mask"], rnd["weight"], rnd["gout"],
+                                                     c["bias"], **kw)
+    t = lambda a: torch.from_numpy(a).to(DEV).to(dtype).requires_grad_(True)
+    x, off, m, w = t(inp["x"]), t(inp["offset"]), t(inp["mask"]), t(inp["weight"])
+    out = pkg.modulated_deform_conv(x, off, m, w, None, c["stride"], c["pad"], c["dil"], c["groups"], c["dg"])
+    assert out.dtype == dtype
+    out.backward(torch.from_numpy(inp["gout"]).to(DEV).to(dtype))
+    assert cases.relerr(out.detach().float().cpu().numpy(), eout) <= tol
+    for got, exp in ((x.grad, egx), (off.grad, egoff), (m.grad, egmask), (w.grad, egw)):
+        assert got.dtype == dtype
+        assert cases.relerr(got.float().cpu().numpy(), exp) <= tol
+    with pytest.raises(RuntimeError):
+        pkg.modulated_deform_conv(x.double(), off.double(), m.double(), w.double(), None, 1, c["pad"], c["dil"], 1, 1)
+    with pytest.raises(RuntimeError):
+        pkg.modulated_deform_conv(x.float(), off, m, w, None, 1, c["pad"], c["dil"], 1, 1)   # mixed dtypes
+
+
 # ---------------------------------------------------------------- the reference's own self-tests, on the GPU
 def test_ref_selftest_zero_offset_equals_conv2d_gpu():
     # detseg/ops/dcn/test.py:17-94 (a),(b)
