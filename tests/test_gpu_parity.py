@@ -205,6 +205,40 @@ def test_backward_recompute_path_matches_saved_columns_path(c, monkeypatch):
     _assert_case(c, res[False][0], res[False][1], exp)
 
 
+def _fuzz_cases():
+    """Seeded random geometries that steer the launch planners through their branches: strip / 2-D tile im2col, tile9 /
+    generic scatter, wide / narrow / idle GEMM tiles, strides, odd sizes, wide and tall maps, large offsets (escapees)."""
+    rng = np.random.default_rng(2024)
+    out = []
+    for i in range(14):
+        k = 3 if i % 7 else (1 if i % 2 else 5)          # mostly 3x3, one 1x1, one 5x5
+        dil = int(rng.integers(1, 4))
+        stride = int(rng.choice([1, 1, 2]))
+        groups = int(rng.choice([1, 1, 2]))
+        dg = int(rng.choice([1, 2, 4]))
+        Ci = int(rng.choice([8, 16, 24, 40])) // (groups * dg) * (groups * dg) or groups * dg * 2
+        Ci = max(Ci, groups * dg * 2)
+        Co = int(rng.choice([6, 10, 16])) * groups
+        H = int(rng.integers(9, 70))
+        W = int(rng.choice([int(rng.integers(9, 60)), int(rng.integers(120, 210))]))
+        out.append(cases.C("fuzz%02d_k%d_c%d_%dx%d_s%d_d%d_g%d_dg%d" % (i, k, Ci, H, W, stride, dil, groups, dg),
+                           N=int(rng.integers(1, 3)), Ci=Ci, Co=Co, H=H, W=W, kh=k, kw=k, stride=stride,
+                           pad=dil * (k // 2), dil=dil, groups=groups, dg=dg, bias=bool(i % 2),
+                           modulated=bool(i % 3), off_scale=float(rng.choice([0.0, 1.0, 2.0, 9.0])), seed=100 + i))
+    return out
+
+
+@pytest.mark.parametrize("c", _fuzz_cases(), ids=lambda c: c["name"])
+def test_fuzz_geometries_against_oracle(c):
+    inp = _r32(cases.make_inputs(c))
+    kw = cases.kwargs(c)
+    exp = dict(out=orc.deform_forward(inp["x"], inp["offset"], inp["mask"], inp["weight"], inp["bias"], **kw))
+    exp["gx"], exp["goff"], exp["gmask"], exp["gw"], exp["gb"] = orc.deform_backward(
+        inp["x"], inp["offset"], inp["mask"], inp["weight"], inp["gout"], c["bias"], **kw)
+    out, grads = _run_hip(c, inp)
+    _assert_case(c, out, grads, exp)
+
+
 @pytest.mark.parametrize("dtype,tol", [(torch.float16, 2e-3), (torch.bfloat16, 1.5e-2)], ids=["f16", "bf16"])
 def test_half_and_bfloat16_tensors_are_computed_in_fp32(dtype, tol):
     """The reference dispatches FLOATING_TYPES_AND_HALF (deform_conv_cuda_kernel.cu:258); here low-precision tensors
