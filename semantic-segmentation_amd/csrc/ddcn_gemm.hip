@@ -68,23 +68,25 @@ struct LoaderMN {
     static constexpr int NV = EXT / 32, TPR = EXT / 4, RSTEP = NT / TPR, LD = EXT;
     unsigned voff[NV];
     float *dst;
-    __device__ __forceinline__ void init(float *lds, long ld, int mn0, int, int t)
+    // per-lane offsets do not depend on the tile: the tile's first column is part of the scalar origin
+    __device__ __forceinline__ void init(float *lds, long ld, int t)
     {
         const int c4 = (t % TPR) * 4, row = t / TPR;
         dst = lds + row * LD + c4;
 #pragma unroll
-        for (int i = 0; i < NV; ++i) voff[i] = (unsigned)(((long)(row + RSTEP * i) * ld + mn0 + c4) * 4);
+        for (int i = 0; i < NV; ++i) voff[i] = (unsigned)(((long)(row + RSTEP * i) * ld + c4) * 4);
     }
-    __device__ __forceinline__ static long origin(long ld, int, int k0) { return (long)k0 * ld; }
+    __device__ __forceinline__ static long origin(long ld, int mn0, int k0) { return (long)k0 * ld + mn0; }
     // elements from the tile origin to the end of the valid rows [k0, kend): the K edge is the descriptor's bound
-    __device__ __forceinline__ static long extent(long ld, long slice_left, int kvalid)
+    // (columns of the last row that would wrap past the row end read zeros; they belong to masked outputs)
+    __device__ __forceinline__ static long extent(long ld, long slice_left, int kvalid, int mn0)
     {
-        const long rows = (long)kvalid * ld;
+        const long rows = (long)kvalid * ld - mn0;
         int sign = (int)((rows - slice_left) >> 32);   // min() through a 32-bit sign test (SALU)
         asm("" : "+s"(sign));
         return sign < 0 ? rows : slice_left;
     }
-    // descriptor base: slice pointer advanced to row k0
+    // descriptor base: slice pointer advanced to (row k0, column mn0)
     __device__ __forceinline__ void load(__amdgpu_buffer_rsrc_t r, f32x4 (&v)[NV]) const
     {
 #pragma unroll
@@ -106,7 +108,9 @@ struct LoaderKC {
     int k4;
     lds_float *d0, *d2;   // LDS rows k4 and k4 + 2 of this thread's column: every ds_write2_b32 offset (<= 1020 B) is
                       // reachable from one of them, so the K loop needs no address arithmetic (no VALU)
-    __device__ __forceinline__ void init(float *lds, long ld, int mn0, int mnlim, int t)
+    // per-lane offsets do not depend on the tile; rows past the M / N edge lie past the end of the slice (the slice IS
+    // [MN][K]) and are rejected by the descriptor
+    __device__ __forceinline__ void init(float *lds, long ld, int t)
     {
         k4 = (t & 7) * 4;
         const int row = t >> 3;
@@ -114,11 +118,10 @@ struct LoaderKC {
         d2 = d0 + 2 * LD;
         asm volatile("" : "+v"(d2));   // a real register, not "d0 + const" rematerialised inside the loop
 #pragma unroll
-        for (int i = 0; i < NV; ++i)
-            voff[i] = (mn0 + row + 32 * i < mnlim) ? (unsigned)(((long)(row + 32 * i) * ld + k4) * 4) : OOB;
+        for (int i = 0; i < NV; ++i) voff[i] = (unsigned)(((long)(row + 32 * i) * ld + k4) * 4);
     }
     __device__ __forceinline__ static long origin(long ld, int mn0, int k0) { return (long)mn0 * ld + k0; }
-    __device__ __forceinline__ static long extent(long, long slice_left, int) { return slice_left; }
+    __device__ __forceinline__ static long extent(long, long slice_left, int, int) { return slice_left; }
     // descriptor base: slice pointer advanced to (row mn0, column k0).  The K edge cuts through rows here, so it is
     // applied in store(): elements with k4 + j >= kvalid are written as zero.
     __device__ __forceinline__ void load(__amdgpu_buffer_rsrc_t r, f32x4 (&v)[NV]) const
@@ -199,15 +202,15 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs &a, float *smem, int gr
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
     LA la; LB lb;
-    la.init(As, a.lda, m0, a.M, t);
-    lb.init(Bs, a.ldb, n0, a.N, t);
+    la.init(As, a.lda, t);
+    lb.init(Bs, a.ldb, t);
     f32x4 ra[LA::NV], rb[LB::NV];
 
     auto gload = [&](int k0) {
         const int kvalid = max(kend - k0, 0);   // 0 past the end: [K][MN] operands read zeros, [MN][K] ones are masked in store()
         const long oa = LA::origin(a.lda, m0, k0), ob = LB::origin(a.ldb, n0, k0);
-        la.load(make_rsrc(A + oa, LA::extent(a.lda, nA - oa, kvalid)), ra);
-        lb.load(make_rsrc(B + ob, LB::extent(a.ldb, nB - ob, kvalid)), rb);
+        la.load(make_rsrc(A + oa, LA::extent(a.lda, nA - oa, kvalid, m0)), ra);
+        lb.load(make_rsrc(B + ob, LB::extent(a.ldb, nB - ob, kvalid, n0)), rb);
     };
     auto sstore = [&](int k0) {
         const int kvalid = kend - k0;
