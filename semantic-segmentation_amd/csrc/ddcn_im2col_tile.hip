@@ -92,6 +92,19 @@ __global__ __launch_bounds__(IT, 2) void im2col_tile_kernel(Im2colTileArgs a)
     const __amdgpu_buffer_rsrc_t rx = mk_rsrc(a.x + (long)n * g.C * HW, (long)g.C * HW * 4);
     const __amdgpu_buffer_rsrc_t rcol = mk_rsrc(a.col + (long)n * g.C * K2 * a.ld, (long)g.C * K2 * a.ld * 4);
 
+    // ---- per-tap sample state (registers, whole channel group)
+    // the offsets / masks go in flight first; the patch offsets below are computed while they travel
+    float roh[K2], row_[K2], rm[K2];
+    {
+        const float *off = a.offset + ((long)n * g.dg + dgi) * 2 * K2 * a.P + p;
+        const float *msk = MOD ? a.mask + ((long)n * g.dg + dgi) * K2 * a.P + p : nullptr;
+#pragma unroll
+        for (int k = 0; k < K2; ++k) {
+            roh[k] = live ? off[(long)(2 * k) * a.P] : 0.f;
+            row_[k] = live ? off[(long)(2 * k + 1) * a.P] : 0.f;
+            rm[k] = (MOD && live) ? msk[(long)k * a.P] : 1.f;
+        }
+    }
     // ---- per-thread staging offsets: cell i = t + 256*j of the patch -> byte offset inside one channel plane
     unsigned soff[NCELL];
 #pragma unroll
@@ -102,22 +115,19 @@ __global__ __launch_bounds__(IT, 2) void im2col_tile_kernel(Im2colTileArgs a)
         soff[j] = (i < a.RS && y >= 0 && y < g.H && xx >= 0 && xx < g.W) ? (unsigned)((y * g.W + xx) * 4) : OOBV;
     }
 
-    // ---- per-tap sample state (registers, whole channel group)
     int cell[K2];        // patch cell of the (hl, wl) corner; -1: escapee (gather from global); -2: invalid sample
     float bw1[K2], bw2[K2], bw3[K2], bw4[K2], fm[K2];   // bilinear weights (K:93-110) and mask
     int ghw[K2];         // (hl << 16) | (wl & 0xffff) for the escapee path
     {
-        const float *off = a.offset + ((long)n * g.dg + dgi) * 2 * K2 * a.P + p;
-        const float *msk = MOD ? a.mask + ((long)n * g.dg + dgi) * K2 * a.P + p : nullptr;
         const int h_in = ho * g.sh - g.ph, w_in = wo * g.sw - g.pw;
 #pragma unroll
         for (int k = 0; k < K2; ++k) {
             const int i = k / 3, j = k - 3 * i;
-            float h = 0.f, w = 0.f, m = 1.f;
+            float h = 0.f, w = 0.f;
+            const float m = rm[k];
             if (live) {
-                h = (float)(h_in + i * g.dh) + off[(long)(2 * k) * a.P];
-                w = (float)(w_in + j * g.dw) + off[(long)(2 * k + 1) * a.P];
-                if (MOD) m = msk[(long)k * a.P];
+                h = (float)(h_in + i * g.dh) + roh[k];
+                w = (float)(w_in + j * g.dw) + row_[k];
             }
             const float fhl = floorf(h), fwl = floorf(w);
             const float lh = h - fhl, lw = w - fwl;
