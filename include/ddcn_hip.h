@@ -107,6 +107,15 @@ int ddcn_bias_grad_f32(const float *grad_out, float *gb, const ddcn_geom *g, voi
 int ddcn_deform_conv_forward_f32(const float *x, const float *weight, const float *bias, const float *offset,
                                  float *out, void *workspace, size_t workspace_bytes, const ddcn_geom *g,
                                  void *stream);
+/* No counterpart in the reference's extension: deform_conv forward for FEW output channels (the 9-channel mask branch
+ * of the DDCN layer, PY:438-446 and PY:457-458, which the reference computes as im2col + a 9-row GEMM + sigmoid), as
+ * one direct kernel: the bilinear samples are multiplied into the output channels in registers, no columns are
+ * written.  out = sigmoid ? 1/(1+exp(-v)) : v with v = bias + W * sample(x, offset).  Covered: 3x3, groups 1,
+ * deformable_groups 1, Co <= 12; anything else runs columns + GEMM (+ activation) inside the same call.
+ * workspace as for ddcn_deform_conv_forward_f32. */
+int ddcn_deform_conv_direct_forward_f32(const float *x, const float *weight, const float *bias, const float *offset,
+                                        float *out, int sigmoid, void *workspace, size_t workspace_bytes,
+                                        const ddcn_geom *g, void *stream);
 /* replaces deform_conv_cuda_backward (H:253-367) */
 int ddcn_deform_conv_backward_f32(const float *x, const float *weight, const float *offset, const float *grad_out,
                                   float *gx, float *goff, float *gw, float *gb, void *workspace,

@@ -230,6 +230,23 @@ int ddcn_deform_conv_forward_f32(const float *x, const float *weight, const floa
     return deform_forward(x, weight, bias, offset, nullptr, out, workspace, workspace_bytes, g, stream);
 }
 
+int ddcn_deform_conv_direct_forward_f32(const float *x, const float *weight, const float *bias, const float *offset,
+                                        float *out, int sigmoid, void *workspace, size_t workspace_bytes,
+                                        const ddcn_geom *g, void *stream)
+{
+    REQUIRE(x); REQUIRE(weight); REQUIRE(offset); REQUIRE(out);
+    TRY(check_geom(g));
+    TRY(check_ws(g, workspace, workspace_bytes));
+    bool handled = false;
+    TRY(launch_skinny_forward(x, offset, weight, bias, out, sigmoid, workspace, workspace_bytes, *g, (hipStream_t)stream,
+                              &handled));
+    if (handled) return DDCN_OK;
+    // geometry outside the direct kernel: columns + GEMM, then the activation
+    TRY(deform_forward(x, weight, bias, offset, nullptr, out, workspace, workspace_bytes, g, stream));
+    if (sigmoid) TRY(launch_sigmoid_inplace(out, (long)g->N * g->Co * g->Ho * g->Wo, (hipStream_t)stream));
+    return DDCN_OK;
+}
+
 int ddcn_deform_conv_backward_f32(const float *x, const float *weight, const float *offset, const float *grad_out,
                                   float *gx, float *goff, float *gw, float *gb, void *workspace,
                                   size_t workspace_bytes, const ddcn_geom *g, void *stream)

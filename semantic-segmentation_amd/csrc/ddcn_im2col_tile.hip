@@ -41,6 +41,10 @@ struct Im2colTileArgs {
     int RH, RW, RS;
     int dbuf;       // 1: two LDS patch buffers (one barrier per chunk), 0: one buffer (two barriers, half the LDS)
     int strip;      // 1: tile = 256 consecutive pixels (full-width patch rows), 0: TH x TW tile
+    // direct mode (SKW > 0): no columns; partial outputs part[grp][n][Co][P] = sum over the group's channels of w * sample
+    const float *sk_w;   // weight [Co][C][3][3]
+    float *sk_part;
+    int sk_co;
 };
 
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t mk_rsrc(const void *base, long bytes)
@@ -49,7 +53,13 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t mk_rsrc(const void *base, long
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(base), 0, n, 0x00020000);
 }
 
-template <bool MOD, int NCELL>
+// SKW = 0: im2col (writes the columns).  SKW = 12: direct convolution for <= 12 output channels (the 9-channel mask
+// branch of the DDCN layer, detseg/ops/dcn/deform_conv.py:438-446, 458): the sampled values never leave the
+// registers, each is multiplied into the output channels with weights staged in LDS next to the patch
+// ([channel][tap][12], read as broadcast ds_read_b128), and the workgroup writes one partial sum per output channel.
+constexpr int SKMAX = 12;
+
+template <bool MOD, int NCELL, int SKW>
 __global__ __launch_bounds__(IT, 2) void im2col_tile_kernel(Im2colTileArgs a)
 {
     constexpr int K2 = 9;
@@ -148,6 +158,29 @@ __global__ __launch_bounds__(IT, 2) void im2col_tile_kernel(Im2colTileArgs a)
     f32x4 *buf0 = reinterpret_cast<f32x4 *>(smem);
     f32x4 *buf1 = buf0 + a.RS;
     float stg[NCELL][CC];
+    // direct mode: weights of the chunk, wl[(cc * 9 + k) * 12 + co], two per thread (432 floats)
+    float *wl = smem + (size_t)(a.dbuf ? 2 : 1) * a.RS * CC;
+    float wreg[2] = {0.f, 0.f};
+    float sacc[SKW ? SKW : 1];
+#pragma unroll
+    for (int i = 0; i < (SKW ? SKW : 1); ++i) sacc[i] = 0.f;
+    auto wstage_load = [&](int c0) {
+        if (SKW) {
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+                const int i = t + IT * r;
+                const int co = i % SKW, ck = i / SKW;          // ck = cc * 9 + k
+                wreg[r] = (i < CC * K2 * SKW && co < a.sk_co) ? a.sk_w[((long)co * g.C + c0 + ck / K2) * K2 + ck % K2] : 0.f;
+            }
+        }
+    };
+    auto wstage_store = [&]() {
+        if (SKW) {
+#pragma unroll
+            for (int r = 0; r < 2; ++r)
+                if (t + IT * r < CC * K2 * SKW) wl[t + IT * r] = wreg[r];
+        }
+    };
 
     auto stage_load = [&](int c0) {
 #pragma unroll
@@ -167,7 +200,9 @@ __global__ __launch_bounds__(IT, 2) void im2col_tile_kernel(Im2colTileArgs a)
     };
 
     stage_load(cg0);
+    wstage_load(cg0);
     stage_store(buf0);
+    wstage_store();
     __syncthreads();
 
     const unsigned pvo = (unsigned)(p * 4);
@@ -176,7 +211,7 @@ __global__ __launch_bounds__(IT, 2) void im2col_tile_kernel(Im2colTileArgs a)
         const int c0 = cg0 + ch * CC;
         const f32x4 *cur = (a.dbuf && (ch & 1)) ? buf1 : buf0;
         f32x4 *nxt = (a.dbuf && !(ch & 1)) ? buf1 : buf0;
-        if (ch + 1 < nchunks) stage_load(c0 + CC);
+        if (ch + 1 < nchunks) { stage_load(c0 + CC); wstage_load(c0 + CC); }
         __builtin_amdgcn_sched_barrier(0);
         if (live) {
 #pragma unroll
@@ -193,15 +228,25 @@ __global__ __launch_bounds__(IT, 2) void im2col_tile_kernel(Im2colTileArgs a)
                         float val = (w1 * a1[cc] + w2 * a2[cc] + w3 * a3[cc] + w4 * a4[cc]);
                         if (MOD) val = val * fm[k];
                         val = cell[k] < 0 ? 0.f : val;
-                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, val), rcol, pvo,
-                                                              rowk + cc * rstep, 0);
+                        if (SKW) {
+                            const f32x4 *wv = reinterpret_cast<const f32x4 *>(wl + (cc * K2 + k) * SKW);
+#pragma unroll
+                            for (int q = 0; q < SKW / 4; ++q) {
+                                const f32x4 w4v = wv[q];
+                                sacc[4 * q + 0] += w4v.x * val; sacc[4 * q + 1] += w4v.y * val;
+                                sacc[4 * q + 2] += w4v.z * val; sacc[4 * q + 3] += w4v.w * val;
+                            }
+                        } else {
+                            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, val), rcol, pvo,
+                                                                  rowk + cc * rstep, 0);
+                        }
                     }
                 }
             }
         }
         __builtin_amdgcn_sched_barrier(0);
         if (!a.dbuf) __syncthreads();   // every wave is done reading the single buffer
-        if (ch + 1 < nchunks) stage_store(nxt);
+        if (ch + 1 < nchunks) { stage_store(nxt); wstage_store(); }
         __syncthreads();
     }
     // ---- escapees: samples whose corners leave the staged patch, gathered from global memory once per
@@ -222,25 +267,45 @@ __global__ __launch_bounds__(IT, 2) void im2col_tile_kernel(Im2colTileArgs a)
                     const float v4 = ok4 ? im[g.W + 1] : 0.f;
                     float val = (w1 * v1 + w2 * v2 + w3 * v3 + w4 * v4);
                     if (MOD) val = val * fm[k];
-                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, val), rcol, pvo,
-                                                          (unsigned)(((cg0 + c) * K2 + k) * a.ld * 4), 0);
+                    if (SKW) {
+#pragma unroll
+                        for (int co = 0; co < SKW; ++co)
+                            if (co < a.sk_co) sacc[co] += a.sk_w[((long)co * g.C + cg0 + c) * K2 + k] * val;
+                    } else {
+                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, val), rcol, pvo,
+                                                              (unsigned)(((cg0 + c) * K2 + k) * a.ld * 4), 0);
+                    }
                     im += HW;
                 }
             }
         }
     }
+    if (SKW && live) {
+        float *dst = a.sk_part + (((long)grp * g.N + n) * a.sk_co) * a.P + p;
+#pragma unroll
+        for (int co = 0; co < SKW; ++co)
+            if (co < a.sk_co) dst[(long)co * a.P] = sacc[co];
+    }
 }
 
-// Plans the tiling; *handled = false when this geometry must use the generic kernel.
-int launch_im2col_tiled(const float *x, const float *offset, const float *mask, float *col, const ddcn_geom &g,
-                        hipStream_t stream, bool *handled)
+// direct mode, second step: out[n][co][p] = act(bias[co] + sum over channel groups of part[grp][n][co][p])
+__global__ __launch_bounds__(256) void skinny_finish_kernel(const float *part, const float *bias, float *out, long per_grp,
+                                                            int groups, int co_n, int P, int sigmoid)
 {
-    *handled = false;
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= per_grp) return;
+    float v = bias ? bias[(i / P) % co_n] : 0.f;
+    for (int gq = 0; gq < groups; ++gq) v += part[(long)gq * per_grp + i];
+    out[i] = sigmoid ? 1.f / (1.f + __expf(-v)) : v;
+}
+
+// Plans the tiling (fills the geometry part of a); false when this geometry must use the generic kernel.
+static bool plan_tile(Im2colTileArgs &a, const ddcn_geom &g, long min_wgs)
+{
     const Dims d = dims_of(g);
-    if (g.kh != 3 || g.kw != 3) return DDCN_OK;
-    if (g.H >= 32766 || g.W >= 32766 || d.cpg % CC) return DDCN_OK;
-    if ((long)g.C * d.K2 * d.ld * 4 >= (1L << 31) || (long)g.C * g.H * g.W * 4 >= (1L << 31)) return DDCN_OK;
-    Im2colTileArgs a{};
+    if (g.kh != 3 || g.kw != 3) return false;
+    if (g.H >= 32766 || g.W >= 32766 || d.cpg % CC) return false;
+    if ((long)g.C * d.K2 * d.ld * 4 >= (1L << 31) || (long)g.C * g.H * g.W * 4 >= (1L << 31)) return false;
     // tile width: least padding waste among 16..32 (or the whole row when narrower)
     int TW;
     if (g.Wo <= 32) {
@@ -281,40 +346,44 @@ int launch_im2col_tiled(const float *x, const float *offset, const float *mask, 
             ok = true;
         }
     }
-    if (!ok) return DDCN_OK;
-    // channel group per workgroup: amortises the sample set-up, but keep >= ~1500 workgroups in the launch
+    if (!ok) return false;
+    // channel group per workgroup: amortises the sample set-up, but keep enough workgroups in the launch
     int CG = d.cpg;
-    while (CG % (2 * CC) == 0 && (long)a.tiles * g.N * (g.C / CG) < 1536) CG /= 2;
+    while (CG % (2 * CC) == 0 && (long)a.tiles * g.N * (g.C / CG) < min_wgs) CG /= 2;
     if (env_cg > 0 && d.cpg % env_cg == 0 && env_cg % CC == 0) CG = env_cg;
     a.CG = CG;
     a.groups = g.C / CG;
-    *handled = true;
-    a.x = x; a.offset = offset; a.mask = mask; a.col = col;
     a.g = g; a.P = d.P; a.cpg = d.cpg; a.ld = d.ld;
-    const long nwg = (long)a.tiles * a.groups;
-    if (nwg > 0x7fffffffL || g.N > 65535) return fail(DDCN_ERR_UNSUPPORTED, "im2col_tile: grid too large");
-    dim3 grid((unsigned)nwg, 1, g.N);
     static const int env_dbuf = getenv("DDCN_IM2COL_DBUF") ? atoi(getenv("DDCN_IM2COL_DBUF")) : 0;
     a.dbuf = env_dbuf;
-    const size_t smem = (size_t)(a.dbuf ? 2 : 1) * a.RS * CC * sizeof(float);
+    return true;
+}
+
+template <int SKW>
+static int run_tile(const Im2colTileArgs &a, bool mod, hipStream_t stream, const char *what)
+{
+    const long nwg = (long)a.tiles * a.groups;
+    if (nwg > 0x7fffffffL || a.g.N > 65535) return fail(DDCN_ERR_UNSUPPORTED, "%s: grid too large", what);
+    dim3 grid((unsigned)nwg, 1, a.g.N);
+    const size_t smem = (size_t)(a.dbuf ? 2 : 1) * a.RS * CC * sizeof(float) + (SKW ? (size_t)CC * 9 * SKW * sizeof(float) : 0);
     const int ncell = (a.RS + IT - 1) / IT;
-#define DDCN_IM2COL_LAUNCH(NC)                                                                         \
-    do {                                                                                               \
-        if (mask)                                                                                      \
-            hipLaunchKernelGGL((im2col_tile_kernel<true, NC>), grid, dim3(IT), smem, stream, a);       \
-        else                                                                                           \
-            hipLaunchKernelGGL((im2col_tile_kernel<false, NC>), grid, dim3(IT), smem, stream, a);      \
+#define DDCN_IM2COL_LAUNCH(NC)                                                                              \
+    do {                                                                                                    \
+        if (mod)                                                                                            \
+            hipLaunchKernelGGL((im2col_tile_kernel<true, NC, SKW>), grid, dim3(IT), smem, stream, a);       \
+        else                                                                                                \
+            hipLaunchKernelGGL((im2col_tile_kernel<false, NC, SKW>), grid, dim3(IT), smem, stream, a);      \
     } while (0)
     hipError_t e = hipSuccess;
     if (smem > 64 * 1024) {
         // > 64 KiB of dynamic LDS needs the opt-in (set for every instantiation that can be launched below)
-        const void *fns[] = {(const void *)&im2col_tile_kernel<true, 10>, (const void *)&im2col_tile_kernel<false, 10>,
-                             (const void *)&im2col_tile_kernel<true, 12>, (const void *)&im2col_tile_kernel<false, 12>,
-                             (const void *)&im2col_tile_kernel<true, 8>, (const void *)&im2col_tile_kernel<false, 8>,
-                             (const void *)&im2col_tile_kernel<true, 6>, (const void *)&im2col_tile_kernel<false, 6>};
+        const void *fns[] = {(const void *)&im2col_tile_kernel<true, 10, SKW>, (const void *)&im2col_tile_kernel<false, 10, SKW>,
+                             (const void *)&im2col_tile_kernel<true, 12, SKW>, (const void *)&im2col_tile_kernel<false, 12, SKW>,
+                             (const void *)&im2col_tile_kernel<true, 8, SKW>, (const void *)&im2col_tile_kernel<false, 8, SKW>,
+                             (const void *)&im2col_tile_kernel<true, 6, SKW>, (const void *)&im2col_tile_kernel<false, 6, SKW>};
         for (const void *fn : fns)
             if (e == hipSuccess) e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-        if (e != hipSuccess) return fail(DDCN_ERR_LAUNCH, "im2col_tile: hipFuncSetAttribute: %s", hipGetErrorString(e));
+        if (e != hipSuccess) return fail(DDCN_ERR_LAUNCH, "%s: hipFuncSetAttribute: %s", what, hipGetErrorString(e));
     }
     if (ncell <= 2) DDCN_IM2COL_LAUNCH(2);
     else if (ncell <= 4) DDCN_IM2COL_LAUNCH(4);
@@ -323,7 +392,54 @@ int launch_im2col_tiled(const float *x, const float *offset, const float *mask, 
     else if (ncell <= 10) DDCN_IM2COL_LAUNCH(10);
     else DDCN_IM2COL_LAUNCH(12);
 #undef DDCN_IM2COL_LAUNCH
-    return check_launch("im2col_tile");
+    return check_launch(what);
+}
+
+// *handled = false when this geometry must use the generic kernel.
+int launch_im2col_tiled(const float *x, const float *offset, const float *mask, float *col, const ddcn_geom &g,
+                        hipStream_t stream, bool *handled)
+{
+    *handled = false;
+    Im2colTileArgs a{};
+    if (!plan_tile(a, g, 1536)) return DDCN_OK;
+    *handled = true;
+    a.x = x; a.offset = offset; a.mask = mask; a.col = col;
+    return run_tile<0>(a, mask != nullptr, stream, "im2col_tile");
+}
+
+// Direct deformable convolution for <= 12 output channels (no columns, no GEMM): out = act(bias + W * sample(x)).
+// workspace: groups * N * Co * P floats of partial sums (groups = channel groups chosen by the planner).
+// *handled = false: geometry not covered (the caller then composes im2col + GEMM).
+int launch_skinny_forward(const float *x, const float *offset, const float *weight, const float *bias, float *out,
+                          int sigmoid, void *ws, size_t ws_bytes, const ddcn_geom &g, hipStream_t stream, bool *handled)
+{
+    *handled = false;
+    if (g.groups != 1 || g.dg != 1 || g.Co > SKMAX) return DDCN_OK;
+    Im2colTileArgs a{};
+    if (!plan_tile(a, g, 1024)) return DDCN_OK;
+    const long per_grp = (long)g.N * g.Co * a.P;
+    if ((size_t)a.groups * per_grp * sizeof(float) > ws_bytes) return DDCN_OK;
+    *handled = true;
+    a.x = x; a.offset = offset; a.mask = nullptr; a.col = nullptr;
+    a.sk_w = weight; a.sk_part = (float *)ws; a.sk_co = g.Co;
+    const int rc = run_tile<SKMAX>(a, false, stream, "skinny_forward");
+    if (rc != DDCN_OK) return rc;
+    const long blocks = (per_grp + 255) / 256;
+    if (blocks > 0x7fffffffL) return fail(DDCN_ERR_UNSUPPORTED, "skinny_forward: grid too large");
+    hipLaunchKernelGGL(skinny_finish_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, (const float *)ws, bias, out,
+                       per_grp, a.groups, g.Co, a.P, sigmoid);
+    return check_launch("skinny_finish");
+}
+
+// out[i] = sigmoid(out[i]) (fallback of the direct entry point when the geometry is not covered)
+int launch_sigmoid_inplace(float *out, long count, hipStream_t stream)
+{
+    const long blocks = (count + 255) / 256;
+    if (blocks <= 0) return DDCN_OK;
+    if (blocks > 0x7fffffffL) return fail(DDCN_ERR_UNSUPPORTED, "sigmoid: grid too large");
+    hipLaunchKernelGGL(skinny_finish_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, (const float *)out,
+                       (const float *)nullptr, out, count, 1, 1, 1, 1);
+    return check_launch("sigmoid");
 }
 
 }  // namespace ddcn

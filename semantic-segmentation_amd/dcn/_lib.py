@@ -42,6 +42,7 @@ PROTOTYPES = {
     "ddcn_gemm_gweight_f32": [_P, _P, _P, _G, _P],
     "ddcn_bias_grad_f32": [_P, _P, _G, _P],
     "ddcn_deform_conv_forward_f32": [_P, _P, _P, _P, _P, _P, _SZ, _G, _P],
+    "ddcn_deform_conv_direct_forward_f32": [_P, _P, _P, _P, _P, ctypes.c_int, _P, _SZ, _G, _P],
     "ddcn_deform_conv_backward_f32": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _SZ, _G, _P],
     "ddcn_modulated_deform_conv_forward_f32": [_P, _P, _P, _P, _P, _P, _P, _SZ, _G, _P],
     "ddcn_modulated_deform_conv_backward_f32": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _SZ, _G, _P],

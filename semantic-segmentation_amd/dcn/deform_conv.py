@@ -331,6 +331,65 @@ class DepthawareConvFunction(Function):
     _infer_shape = staticmethod(_infer_shape)
 
 
+class _DeformConvSigmoidFunction(Function):
+    """sigmoid(deform_conv(input, offset, weight, bias)): the mask branch of the DDCN layer (PY:438-446, 457-458).
+
+    Forward is ONE direct kernel for the few (9) output channels (ddcn_deform_conv_direct_forward_f32: no columns,
+    no 9-row GEMM, sigmoid fused); backward applies sigmoid' and then is DeformConvFunction's backward."""
+
+    @staticmethod
+    def forward(ctx, input, offset, weight, bias, stride, padding, dilation, groups, deformable_groups):
+        ctx.stride, ctx.padding, ctx.dilation = stride, padding, dilation
+        ctx.groups, ctx.deformable_groups = groups, deformable_groups
+        ctx.with_bias = bias is not None
+        if not ctx.with_bias:
+            bias = input.new_empty(1)  # fake tensor
+        if not input.is_cuda:
+            raise NotImplementedError
+        for name, t in (("input", input), ("offset", offset), ("weight", weight), ("bias", bias)):
+            _check_dtype_cuda(name, t, input.dtype)
+        ctx.dtype = input.dtype
+        _contig("input", input)
+        _contig("weight", weight)
+        g = _geom(input, weight, stride, padding, dilation, groups, deformable_groups)
+        _expect_shape("offset", offset, (g.N, deformable_groups * 2 * g.kh * g.kw, g.Ho, g.Wo))
+        offset = offset.contiguous()
+        saved = (input, offset, weight, bias)
+        input, offset, weight, bias = (_f32(t) for t in saved)
+        output = input.new_empty((g.N, g.Co, g.Ho, g.Wo))
+        ws, ws_bytes = _workspace(input, g)
+        with torch.cuda.device(input.device):
+            _lib.check(_lib.lib().ddcn_deform_conv_direct_forward_f32(
+                _lib.ptr(input), _lib.ptr(weight), _lib.ptr(bias) if ctx.with_bias else None, _lib.ptr(offset),
+                _lib.ptr(output), 1, _lib.ptr(ws), ws_bytes, g, _lib.current_stream(input.device)))
+        ctx.save_for_backward(*saved, output)
+        return output if ctx.dtype == torch.float32 else output.to(ctx.dtype)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, grad_output):
+        if not grad_output.is_cuda:
+            raise NotImplementedError
+        input, offset, weight, bias, out = ctx.saved_tensors
+        input, offset, weight, bias = (_f32(t) for t in (input, offset, weight, bias))
+        grad_pre = (_f32(grad_output) * out * (1.0 - out)).contiguous()      # d sigmoid
+        grad_input, grad_offset, grad_weight, grad_bias = _zeros_like_all(input, offset, weight, bias)
+        g = _geom(input, weight, ctx.stride, ctx.padding, ctx.dilation, ctx.groups, ctx.deformable_groups)
+        _expect_shape("grad_output", grad_pre, (g.N, g.Co, g.Ho, g.Wo))
+        ws, ws_bytes = _workspace(input, g)
+        with torch.cuda.device(input.device):
+            _lib.check(_lib.lib().ddcn_deform_conv_backward_f32(
+                _lib.ptr(input), _lib.ptr(weight), _lib.ptr(offset), _lib.ptr(grad_pre), _lib.ptr(grad_input),
+                _lib.ptr(grad_offset), _lib.ptr(grad_weight), _lib.ptr(grad_bias) if ctx.with_bias else None,
+                _lib.ptr(ws), ws_bytes, g, _lib.current_stream(input.device)))
+        if not ctx.with_bias:
+            grad_bias = None
+        if ctx.dtype != torch.float32:
+            grad_input, grad_offset, grad_weight, grad_bias = (
+                None if t is None else t.to(ctx.dtype) for t in (grad_input, grad_offset, grad_weight, grad_bias))
+        return (grad_input, grad_offset, grad_weight, grad_bias, None, None, None, None, None)
+
+
 deform_conv = DeformConvFunction.apply
 modulated_deform_conv = ModulatedDeformConvFunction.apply
 depthaware_conv = DepthawareConvFunction.apply
@@ -484,7 +543,9 @@ class DepthDeformConvPack(ModulatedDeformConv):
         # read the first 2*K2 offset channels of each image; state that explicitly instead of by pointer luck
         k2x2 = 2 * self.kernel_size[0] * self.kernel_size[1]
         mask_offset = offset if self.deformable_groups == 1 else offset[:, :k2x2].contiguous()
-        mask = torch.sigmoid(self.conv_mask(depth, mask_offset))
+        cm = self.conv_mask
+        mask = _DeformConvSigmoidFunction.apply(depth, mask_offset, cm.weight, cm.bias, cm.stride, cm.padding,
+                                                cm.dilation, cm.groups, cm.deformable_groups)
         self.offset, self.mask = offset, mask
         return modulated_deform_conv(x, offset, mask, self.weight, self.bias,
                                      self.stride, self.padding, self.dilation,

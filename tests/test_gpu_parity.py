@@ -205,6 +205,37 @@ def test_backward_recompute_path_matches_saved_columns_path(c, monkeypatch):
     _assert_case(c, res[False][0], res[False][1], exp)
 
 
+@pytest.mark.parametrize("geo", [
+    dict(Ci=32, Co=9, H=40, W=37, k=3, dil=2, off=2.0),     # the direct kernel (mask branch shape)
+    dict(Ci=16, Co=9, H=23, W=150, k=3, dil=1, off=9.0),    # wide map, most samples leave the staged patch
+    dict(Ci=16, Co=12, H=9, W=9, k=3, dil=4, off=1.0),      # Co = 12, tiny map
+    dict(Ci=16, Co=16, H=12, W=12, k=3, dil=1, off=2.0),    # Co > 12: columns + GEMM fallback inside the entry point
+    dict(Ci=8, Co=9, H=12, W=12, k=1, dil=1, off=2.0),      # 1x1: fallback
+], ids=lambda d: "c%d_co%d_%dx%d_k%d" % (d["Ci"], d["Co"], d["H"], d["W"], d["k"]))
+def test_direct_forward_with_sigmoid_matches_composition(geo):
+    """ddcn_deform_conv_direct_forward_f32 (no counterpart in the reference: PY:457-458 fused) against
+    sigmoid(deform_conv(...)) of the ordinary entry points, forward and all gradients, and against the oracle."""
+    mod = importlib.import_module("semantic-segmentation_amd.dcn.deform_conv")
+    c = cases.C("direct", N=2, Ci=geo["Ci"], Co=geo["Co"], H=geo["H"], W=geo["W"], kh=geo["k"], kw=geo["k"],
+                pad=geo["dil"] * (geo["k"] // 2), dil=geo["dil"], bias=True, modulated=False, off_scale=geo["off"], seed=77)
+    inp = _r32(cases.make_inputs(c))
+    kw = cases.kwargs(c)
+    pre = orc.deform_forward(inp["x"], inp["offset"], None, inp["weight"], inp["bias"], **kw)
+    exp = 1.0 / (1.0 + np.exp(-pre))
+    res = []
+    for fused in (True, False):
+        x, off, w, b = _t(inp["x"], True), _t(inp["offset"], True), _t(inp["weight"], True), _t(inp["bias"], True)
+        if fused:
+            out = mod._DeformConvSigmoidFunction.apply(x, off, w, b, 1, c["pad"], c["dil"], 1, 1)
+        else:
+            out = torch.sigmoid(pkg.deform_conv(x, off, w, b, 1, c["pad"], c["dil"], 1, 1))
+        out.backward(_t(inp["gout"]))
+        res.append([t.detach().cpu().numpy() for t in (out, x.grad, off.grad, w.grad, b.grad)])
+    assert cases.relerr(res[0][0], exp) <= FWD_TOL
+    for got, ref in zip(res[0], res[1]):
+        assert cases.relerr(got, ref.astype(np.float64)) <= BWD_TOL
+
+
 def _fuzz_cases():
     """Seeded random geometries that steer the launch planners through their branches: strip / 2-D tile im2col, tile9 /
     generic scatter, wide / narrow / idle GEMM tiles, strides, odd sizes, wide and tall maps, large offsets (escapees)."""
