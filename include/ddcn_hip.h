@@ -151,6 +151,41 @@ int ddcn_depthaware_conv_backward_f32(const float *x, const float *depth, const 
                                       const float *grad_out, float *gx, float *gw, float *gb, void *workspace,
                                       size_t workspace_bytes, const ddcn_geom *g, void *stream);
 
+/* ---------------------------------------------------------------- deformable PS-RoI pooling
+ * Replaces the reference's second extension, `detseg.ops.dcn.deform_pool_cuda`:
+ *   PP = detseg/ops/dcn/deform_pool.py
+ *   PH = detseg/ops/dcn/src/deform_pool_cuda.cpp      (pybind11 module, PH:84-90)
+ *   PK = detseg/ops/dcn/src/deform_pool_cuda_kernel.cu
+ * data[B,C,H,W] with C = out_channels*group_size^2 score maps, rois[R,5] = (batch index, x1, y1, x2, y2) in image
+ * pixels, offset[R,trans_channels,part_size,part_size] (channel 2k = x, 2k+1 = y shift of class k, in units of the
+ * RoI size / trans_std; NULL and ignored when no_trans), out / out_count / grad_out[R,out_channels,pooled,pooled].
+ * The struct carries the scalar arguments of PH:34-38 in that order. */
+typedef struct ddcn_roi_geom {
+    int B, C, H, W;        /* data */
+    int R;                 /* number of RoIs (0 is allowed: nothing is launched) */
+    int out_channels;      /* output_dim */
+    int pooled;            /* pooled_size (out_size; square, PP:25-29) */
+    int group_size;
+    int part_size;
+    int sample_per_part;
+    int trans_channels;    /* offset.size(1); ignored when no_trans (PH:46) */
+    int no_trans;
+    float spatial_scale;
+    float trans_std;       /* in [0, 1] (PP:40) */
+} ddcn_roi_geom;
+
+/* replaces deform_psroi_pooling_cuda_forward (PH:34-56, kernel PK:53-139).  Writes out and out_count (the number of
+ * samples each bin kept, which backward divides by).  A RoI whose batch index is outside [0, B) pools nothing
+ * (output 0, count 0); the reference reads out of bounds there. */
+int ddcn_deform_psroi_pool_forward_f32(const float *data, const float *rois, const float *offset, float *out,
+                                       float *out_count, const ddcn_roi_geom *g, void *stream);
+/* replaces deform_psroi_pooling_cuda_backward (PH:58-82, kernel PK:141-263).  ACCUMULATES into grad_data and
+ * grad_offset (zero-fill them first, as PP:66-68 does); grad_offset may be NULL when no_trans.  No gradient flows to
+ * rois (PP:67).  Limits: pooled, part_size <= 32 (DDCN_ERR_UNSUPPORTED beyond). */
+int ddcn_deform_psroi_pool_backward_f32(const float *grad_out, const float *data, const float *rois,
+                                        const float *offset, const float *out_count, float *grad_data,
+                                        float *grad_offset, const ddcn_roi_geom *g, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

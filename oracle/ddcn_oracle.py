@@ -199,3 +199,50 @@ def depthaware_backward(x, depth, weight, grad_out, with_bias=False, stride=1, p
     _call("ddcn_ref_depthaware_backward", dt, _p(x), _p(depth), _p(weight), _p(grad_out), _p(gx), _p(gw), _p(gb),
           _p(col), ctypes.byref(g))
     return gx, gw, gb
+
+
+# ----------------------------------------------------------------------------- deformable PS-RoI pooling
+class RoiGeom(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_int) for n in
+                ("B", "C", "H", "W", "R", "out_channels", "pooled", "group_size", "part_size",
+                 "sample_per_part", "trans_channels", "no_trans")] + \
+               [("spatial_scale", ctypes.c_float), ("trans_std", ctypes.c_float)]
+
+
+def _roi_geom(data, rois, offset, spatial_scale, out_size, out_channels, no_trans, group_size, part_size,
+              sample_per_part, trans_std):
+    # argument meaning of DeformRoIPoolingFunction.forward, detseg/ops/dcn/deform_pool.py:13-38
+    B, C, H, W = data.shape
+    part_size = out_size if part_size is None else part_size
+    tc = 2 if no_trans else offset.shape[1]
+    return RoiGeom(B, C, H, W, rois.shape[0], out_channels, out_size, group_size, part_size, sample_per_part,
+                   tc, int(bool(no_trans)), spatial_scale, trans_std)
+
+
+def psroi_forward(data, rois, offset, spatial_scale, out_size, out_channels, no_trans, group_size=1,
+                  part_size=None, sample_per_part=4, trans_std=0.0):
+    """Returns (output, output_count), both [R, out_channels, out_size, out_size]."""
+    dt = data.dtype.type
+    g = _roi_geom(data, rois, offset, spatial_scale, out_size, out_channels, no_trans, group_size, part_size,
+                  sample_per_part, trans_std)
+    data, rois = _c(data, dt), _c(rois, dt)
+    offset = None if no_trans else _c(offset, dt)
+    out = np.empty((g.R, out_channels, out_size, out_size), dtype=dt)
+    cnt = np.empty_like(out)
+    _call("ddcn_ref_psroi_forward", dt, _p(data), _p(rois), _p(offset), _p(out), _p(cnt), ctypes.byref(g))
+    return out, cnt
+
+
+def psroi_backward(grad_out, data, rois, offset, out_count, spatial_scale, out_size, out_channels, no_trans,
+                   group_size=1, part_size=None, sample_per_part=4, trans_std=0.0):
+    """Returns (grad_data, grad_offset|None)."""
+    dt = data.dtype.type
+    g = _roi_geom(data, rois, offset, spatial_scale, out_size, out_channels, no_trans, group_size, part_size,
+                  sample_per_part, trans_std)
+    grad_out, data, rois, out_count = _c(grad_out, dt), _c(data, dt), _c(rois, dt), _c(out_count, dt)
+    offset = None if no_trans else _c(offset, dt)
+    gdata = np.zeros_like(data)
+    goff = None if no_trans else np.zeros_like(offset)
+    _call("ddcn_ref_psroi_backward", dt, _p(grad_out), _p(data), _p(rois), _p(offset), _p(out_count), _p(gdata),
+          _p(goff), ctypes.byref(g))
+    return gdata, goff

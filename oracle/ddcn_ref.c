@@ -14,7 +14,9 @@
  * reference's own known-answer self-tests, detseg/ops/dcn/test.py:17-267
  * (zero-offset == nn.Conv2d, identity weights, fp64 gradcheck), plus an
  * independently written grid_sample/autograd formulation (tests/indep_ref.py).
- * See tests/test_oracle.py.
+ * See tests/test_oracle.py.  The deformable PS-RoI pooling restatement
+ * (psroi_ref_impl.inc: deform_pool_cuda_kernel.cu) has no reference test at all:
+ * "parity unpinned", see that file's header and tests/test_oracle_psroi.py.
  *
  * Build: make -C oracle   (gcc -O3 -fopenmp -shared; no -march=native: the
  * .so is built in the authoring container and runs on the GPU box's host CPU;
@@ -28,6 +30,13 @@ typedef struct {
     int N, C, H, W, Co, kh, kw, sh, sw, ph, pw, dh, dw, groups, dg, Ho, Wo;
 } ddcn_ref_geom;
 
+/* deformable PS-RoI pooling (psroi_ref_impl.inc); mirrors the argument list of
+ * detseg/ops/dcn/src/deform_pool_cuda.cpp:34-38 */
+typedef struct {
+    int B, C, H, W, R, out_channels, pooled, group_size, part_size, sample_per_part, trans_channels, no_trans;
+    float spatial_scale, trans_std;
+} ddcn_ref_roi_geom;
+
 #if defined(__x86_64__)
 #define GEMM_CLONES __attribute__((target_clones("avx512f", "avx2", "default")))
 #else
@@ -39,6 +48,7 @@ typedef struct {
 #define REXP expf
 #define RFABS fabsf
 #include "ddcn_ref_impl.inc"
+#include "psroi_ref_impl.inc"
 #undef REAL
 #undef SUF
 #undef REXP
@@ -49,6 +59,7 @@ typedef struct {
 #define REXP exp
 #define RFABS fabs
 #include "ddcn_ref_impl.inc"
+#include "psroi_ref_impl.inc"
 #undef REAL
 #undef SUF
 #undef REXP

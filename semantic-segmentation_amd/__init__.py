@@ -6,10 +6,13 @@ The directory name is hyphenated, so import it with
 """
 from .dcn import (DeformConv, DeformConvPack, ModulatedDeformConv, ModulatedDeformConvPack, DepthawareConv,
                   DepthDeformConvPack, DeformConvFunction, ModulatedDeformConvFunction, DepthawareConvFunction,
-                  deform_conv, modulated_deform_conv, depthaware_conv)
+                  deform_conv, modulated_deform_conv, depthaware_conv, DeformRoIPooling, DeformRoIPoolingPack,
+                  ModulatedDeformRoIPoolingPack, DeformRoIPoolingFunction, deform_roi_pooling)
 
 __all__ = [
     'DeformConv', 'DeformConvPack', 'ModulatedDeformConv', 'ModulatedDeformConvPack', 'DepthawareConv',
     'DepthDeformConvPack', 'DeformConvFunction', 'ModulatedDeformConvFunction', 'DepthawareConvFunction',
-    'deform_conv', 'modulated_deform_conv', 'depthaware_conv'
+    'deform_conv', 'modulated_deform_conv', 'depthaware_conv',
+    'DeformRoIPooling', 'DeformRoIPoolingPack', 'ModulatedDeformRoIPoolingPack', 'DeformRoIPoolingFunction',
+    'deform_roi_pooling'
 ]

@@ -328,4 +328,18 @@ int ddcn_depthaware_conv_backward_f32(const float *x, const float *depth, const 
     return DDCN_OK;
 }
 
+int ddcn_deform_psroi_pool_forward_f32(const float *data, const float *rois, const float *offset, float *out,
+                                       float *out_count, const ddcn_roi_geom *g, void *stream)
+{
+    return launch_psroi_forward(data, rois, offset, out, out_count, g, (hipStream_t)stream);
+}
+
+int ddcn_deform_psroi_pool_backward_f32(const float *grad_out, const float *data, const float *rois,
+                                        const float *offset, const float *out_count, float *grad_data,
+                                        float *grad_offset, const ddcn_roi_geom *g, void *stream)
+{
+    return launch_psroi_backward(grad_out, data, rois, offset, out_count, grad_data, grad_offset, g,
+                                 (hipStream_t)stream);
+}
+
 }  // extern "C"

@@ -58,4 +58,10 @@ int launch_gemm_out(const float *weight, const float *col, const float *bias, fl
 int launch_gemm_gcol(const float *weight, const float *gout, float *gcol, const ddcn_geom &g, hipStream_t stream);
 int launch_gemm_gweight(const float *gout, const float *col, float *gw, const ddcn_geom &g, hipStream_t stream);
 
+int launch_psroi_forward(const float *data, const float *rois, const float *trans, float *out, float *out_count,
+                         const ddcn_roi_geom *g, hipStream_t stream);
+int launch_psroi_backward(const float *grad_out, const float *data, const float *rois, const float *trans,
+                          const float *out_count, float *grad_data, float *grad_trans, const ddcn_roi_geom *g,
+                          hipStream_t stream);
+
 }  // namespace ddcn

@@ -1,0 +1,481 @@
+// Deformable position-sensitive RoI pooling for gfx950 (forward and backward).
+//
+// Replaces the two CUDA kernels of detseg/ops/dcn/src/deform_pool_cuda_kernel.cu (PK below):
+//   forward   PK:53-139    one lane per output bin, lanes run along (pw, ph, ctop) so stores coalesce and the
+//                          four corner reads of neighbouring lanes fall into the same lines of one score map;
+//   backward  PK:141-263   two kernels, neither adds to global memory per sample as the CUDA kernel does:
+//     offset gradient      one workgroup per (RoI, offset class, slice of the class's channels).  The bin
+//                          geometry is computed once per workgroup into LDS instead of once per channel; the
+//                          gradient -- two global atomics per SAMPLE in the CUDA kernel, all channels of a
+//                          class onto the same 2*part^2 cells -- is summed per bin in registers, per
+//                          workgroup in LDS, and leaves with one global atomic per cell;
+//     feature gradient     "plane owner": one workgroup per (score map, RoI slice) keeps the whole H*W gradient
+//                          plane in LDS as doubles (ds_add_f64 runs ~9x faster than ds_add_f32 on this chip),
+//                          walks the RoIs of its image, and writes the plane out once.  Consecutive samples
+//                          that fall into the same pixel cell are merged before they touch LDS.  A map too
+//                          large for LDS falls back to global atomics inside the first kernel.
+//
+// Coordinate arithmetic is compiled with contraction off: whether a sample is dropped, and which cell it falls
+// into, are discrete decisions, and they must not depend on where the compiler forms an FMA.
+#include "ddcn_common.h"
+
+#include <stdlib.h>
+
+namespace ddcn {
+namespace {
+
+constexpr int RT = 256;          // threads per workgroup, both kernels
+constexpr int MAX_BINS = 1024;   // pooled^2 and part^2 limits of the backward kernel (LDS tables)
+
+struct RoiArgs {
+    const float *data, *rois, *trans, *cnt, *gout;
+    float *out, *out_cnt, *gdata, *gtrans;
+    int B, C, H, W, R, OC, PS, GS, PART, SPP, NCLS, CEC, no_trans;
+    float scale, tstd;
+    int chunk;  // backward: channels per workgroup
+};
+
+struct RoiBox {
+    float x0, y0, w, h;  // roi_start_w, roi_start_h, roi_width, roi_height
+    int batch;
+};
+
+// PK:79-89
+__device__ __forceinline__ RoiBox roi_box(const float *roi, float scale)
+{
+#pragma clang fp contract(off)
+    RoiBox b;
+    b.batch = (int)roi[0];
+    b.x0 = roundf(roi[1]) * scale - 0.5f;
+    b.y0 = roundf(roi[2]) * scale - 0.5f;
+    const float x1 = (roundf(roi[3]) + 1.f) * scale - 0.5f;
+    const float y1 = (roundf(roi[4]) + 1.f) * scale - 0.5f;
+    // the reference compares against the DOUBLE literal 0.1
+    b.w = (float)fmax((double)(x1 - b.x0), 0.1);
+    b.h = (float)fmax((double)(y1 - b.y0), 0.1);
+    return b;
+}
+
+struct BinGeom {
+    float wstart, hstart;
+    int gofs;   // gh * GS + gw
+    int pidx;   // part_h * PART + part_w
+};
+
+// PK:92-114 for one bin of one (RoI, class)
+__device__ __forceinline__ BinGeom bin_geom(const RoiArgs &a, const RoiBox &b, int n, int cls, int ph, int pw)
+{
+#pragma clang fp contract(off)
+    BinGeom g;
+    const float bin_h = b.h / (float)a.PS, bin_w = b.w / (float)a.PS;
+    const int part_h = (int)floorf((float)ph / (float)a.PS * (float)a.PART);
+    const int part_w = (int)floorf((float)pw / (float)a.PS * (float)a.PART);
+    g.pidx = part_h * a.PART + part_w;
+    float tx = 0.f, ty = 0.f;
+    if (!a.no_trans) {
+        const float *t = a.trans + ((long)n * a.NCLS + cls) * 2 * a.PART * a.PART;
+        tx = t[g.pidx] * a.tstd;
+        ty = t[a.PART * a.PART + g.pidx] * a.tstd;
+    }
+    float wstart = (float)pw * bin_w + b.x0;
+    wstart += tx * b.w;
+    float hstart = (float)ph * bin_h + b.y0;
+    hstart += ty * b.h;
+    g.wstart = wstart;
+    g.hstart = hstart;
+    int gw = (int)floorf((float)pw * (float)a.GS / (float)a.PS);
+    int gh = (int)floorf((float)ph * (float)a.GS / (float)a.PS);
+    gw = min(max(gw, 0), a.GS - 1);
+    gh = min(max(gh, 0), a.GS - 1);
+    g.gofs = gh * a.GS + gw;
+    return g;
+}
+
+// PK:121-128: false when the sample is dropped; otherwise w, h clamped into the map
+__device__ __forceinline__ bool keep_sample(float &w, float &h, int W, int H)
+{
+    if (w < -0.5f || w > (float)W - 0.5f || h < -0.5f || h > (float)H - 0.5f) return false;
+    w = fminf(fmaxf(w, 0.f), (float)W - 1.f);
+    h = fminf(fmaxf(h, 0.f), (float)H - 1.f);
+    return true;
+}
+
+__global__ __launch_bounds__(RT) void psroi_forward_kernel(const RoiArgs a)
+{
+    const long total = (long)a.R * a.OC * a.PS * a.PS;
+    for (long index = (long)blockIdx.x * RT + threadIdx.x; index < total; index += (long)gridDim.x * RT) {
+        const int pw = (int)(index % a.PS);
+        const int ph = (int)(index / a.PS % a.PS);
+        const int ctop = (int)(index / ((long)a.PS * a.PS) % a.OC);
+        const int n = (int)(index / ((long)a.PS * a.PS * a.OC));
+        const RoiBox b = roi_box(a.rois + (long)n * 5, a.scale);
+        float sum = 0.f;
+        int count = 0;
+        if (b.batch >= 0 && b.batch < a.B) {  // a RoI naming an image the batch lacks pools nothing
+            const BinGeom g = bin_geom(a, b, n, ctop / a.CEC, ph, pw);
+            float sub_w, sub_h;
+            {
+#pragma clang fp contract(off)
+                sub_h = b.h / (float)a.PS / (float)a.SPP;
+                sub_w = b.w / (float)a.PS / (float)a.SPP;
+            }
+            const float *plane = a.data + ((long)b.batch * a.C + (long)ctop * a.GS * a.GS + g.gofs) * a.H * a.W;
+            for (int ih = 0; ih < a.SPP; ++ih) {
+                for (int iw = 0; iw < a.SPP; ++iw) {
+                    float w, h;
+                    {
+#pragma clang fp contract(off)
+                        w = g.wstart + (float)iw * sub_w;
+                        h = g.hstart + (float)ih * sub_h;
+                    }
+                    if (!keep_sample(w, h, a.W, a.H)) continue;
+                    // PK:33-50
+                    const int x1 = (int)floorf(w), x2 = (int)ceilf(w);
+                    const int y1 = (int)floorf(h), y2 = (int)ceilf(h);
+                    const float dx = w - (float)x1, dy = h - (float)y1;
+                    const float v11 = plane[y1 * a.W + x1], v12 = plane[y2 * a.W + x1];
+                    const float v21 = plane[y1 * a.W + x2], v22 = plane[y2 * a.W + x2];
+                    sum += (1.f - dx) * (1.f - dy) * v11 + (1.f - dx) * dy * v12 + dx * (1.f - dy) * v21 +
+                           dx * dy * v22;
+                    ++count;
+                }
+            }
+        }
+        a.out[index] = count == 0 ? 0.f : sum / (float)count;
+        a.out_cnt[index] = (float)count;
+    }
+}
+
+// Adds the pending cell (base pixel p, its right/lower neighbours at +sx / +sy) to the feature gradient.
+__device__ __forceinline__ void flush_cell(float *gplane, int p, int sx, int sy, float a00, float a01, float a10,
+                                           float a11)
+{
+    if (a00 != 0.f) atomicAdd(gplane + p, a00);
+    if (a01 != 0.f) atomicAdd(gplane + p + sy, a01);
+    if (a10 != 0.f) atomicAdd(gplane + p + sx, a10);
+    if (a11 != 0.f) atomicAdd(gplane + p + sx + sy, a11);
+}
+
+// DATA: also scatter the feature gradient (global atomics); otherwise only the offset gradient.
+template <bool DATA>
+__global__ __launch_bounds__(RT) void psroi_backward_kernel(const RoiArgs a)
+{
+    __shared__ float s_wstart[MAX_BINS], s_hstart[MAX_BINS];
+    __shared__ int s_gofs[MAX_BINS], s_pidx[MAX_BINS];
+    __shared__ float s_gt[2 * MAX_BINS];
+
+    const int n = blockIdx.x / a.NCLS, cls = blockIdx.x % a.NCLS;
+    const int c_begin = blockIdx.y * a.chunk, c_end = min(c_begin + a.chunk, a.CEC);
+    const int bins = a.PS * a.PS, parts = a.PART * a.PART;
+    const RoiBox b = roi_box(a.rois + (long)n * 5, a.scale);
+    if (b.batch < 0 || b.batch >= a.B) return;  // block-uniform: same rule as the forward kernel
+
+    for (int i = threadIdx.x; i < bins; i += RT) {
+        const BinGeom g = bin_geom(a, b, n, cls, i / a.PS, i % a.PS);
+        s_wstart[i] = g.wstart;
+        s_hstart[i] = g.hstart;
+        s_gofs[i] = g.gofs;
+        s_pidx[i] = g.pidx;
+    }
+    for (int i = threadIdx.x; i < 2 * parts; i += RT) s_gt[i] = 0.f;
+    __syncthreads();
+
+    float sub_w, sub_h;
+    {
+#pragma clang fp contract(off)
+        sub_h = b.h / (float)a.PS / (float)a.SPP;
+        sub_w = b.w / (float)a.PS / (float)a.SPP;
+    }
+    const long HW = (long)a.H * a.W;
+    const float *img = a.data + (long)b.batch * a.C * HW;
+    float *gimg = a.gdata + (long)b.batch * a.C * HW;
+    const int items = (c_end - c_begin) * bins;
+    for (int item = threadIdx.x; item < items; item += RT) {
+        const int bin = item % bins;
+        const int ctop = cls * a.CEC + c_begin + item / bins;
+        const long oidx = ((long)n * a.OC + ctop) * bins + bin;
+        const float cnt = a.cnt[oidx];
+        if (cnt <= 0.f) continue;  // PK:203-206
+        const float diff_val = a.gout[oidx] / cnt;
+        const long pofs = ((long)ctop * a.GS * a.GS + s_gofs[bin]) * HW;
+        const float *plane = img + pofs;
+        float *gplane = gimg + pofs;
+        const float wstart = s_wstart[bin], hstart = s_hstart[bin];
+        float tdx = 0.f, tdy = 0.f;
+        // pending cell of the feature gradient
+        int pend = -1, pend_sx = 0, pend_sy = 0;
+        float a00 = 0.f, a01 = 0.f, a10 = 0.f, a11 = 0.f;
+        for (int ih = 0; ih < a.SPP; ++ih) {
+            for (int iw = 0; iw < a.SPP; ++iw) {
+                float w, h;
+                {
+#pragma clang fp contract(off)
+                    w = wstart + (float)iw * sub_w;
+                    h = hstart + (float)ih * sub_h;
+                }
+                if (!keep_sample(w, h, a.W, a.H)) continue;
+                // PK:230-243
+                const int x0 = (int)floorf(w), x1 = (int)ceilf(w);
+                const int y0 = (int)floorf(h), y1 = (int)ceilf(h);
+                const float dx = w - (float)x0, dy = h - (float)y0;
+                const int p = y0 * a.W + x0, sx = x1 - x0, sy = (y1 - y0) * a.W;
+                if (DATA) {
+                    if (p != pend || sx != pend_sx || sy != pend_sy) {
+                        if (pend >= 0) flush_cell(gplane, pend, pend_sx, pend_sy, a00, a01, a10, a11);
+                        pend = p;
+                        pend_sx = sx;
+                        pend_sy = sy;
+                        a00 = a01 = a10 = a11 = 0.f;
+                    }
+                    a00 += (1.f - dx) * (1.f - dy) * diff_val;
+                    a01 += (1.f - dx) * dy * diff_val;
+                    a10 += dx * (1.f - dy) * diff_val;
+                    a11 += dx * dy * diff_val;
+                }
+                if (a.no_trans) continue;
+                // PK:249-256
+                const float U00 = plane[p], U01 = plane[p + sy], U10 = plane[p + sx], U11 = plane[p + sx + sy];
+                tdx += (U11 * dy + U10 * (1.f - dy) - U01 * dy - U00 * (1.f - dy)) * a.tstd * diff_val * b.w;
+                tdy += (U11 * dx + U01 * (1.f - dx) - U10 * dx - U00 * (1.f - dx)) * a.tstd * diff_val * b.h;
+            }
+        }
+        if (DATA && pend >= 0) flush_cell(gplane, pend, pend_sx, pend_sy, a00, a01, a10, a11);
+        if (!a.no_trans) {
+            if (tdx != 0.f) atomicAdd(&s_gt[s_pidx[bin]], tdx);
+            if (tdy != 0.f) atomicAdd(&s_gt[parts + s_pidx[bin]], tdy);
+        }
+    }
+    if (a.no_trans) return;
+    __syncthreads();
+    // PK:258-259, once per cell and workgroup
+    float *gt = a.gtrans + ((long)n * a.NCLS + cls) * 2 * parts;
+    for (int i = threadIdx.x; i < 2 * parts; i += RT) {
+        const float v = s_gt[i];
+        if (v != 0.f) atomicAdd(gt + i, v);
+    }
+}
+
+
+// ---- feature gradient, plane-owner formulation ----
+constexpr int ROI_CHUNK = 1024;           // RoI candidates compacted per pass
+constexpr int PLANE_LDS_MAX = 144 * 1024; // bytes of the double plane a workgroup may hold
+
+__device__ __forceinline__ void lds_add(double *cell, float v)
+{
+    if (v != 0.f) __hip_atomic_fetch_add(cell, (double)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
+// grid.x = B*C score maps, grid.y = RoI slices (RoI n belongs to slice n % gridDim.y).
+__global__ __launch_bounds__(RT) void psroi_backward_plane_kernel(const RoiArgs a)
+{
+    extern __shared__ double s_plane[];               // [H*W]
+    __shared__ int s_bins[MAX_BINS], s_rois[ROI_CHUNK];
+    __shared__ int s_nbins, s_nrois;
+
+    const int b = blockIdx.x / a.C, c = blockIdx.x % a.C;
+    const int gs2 = a.GS * a.GS;
+    const int ctop = c / gs2, gcell = c % gs2, cls = ctop / a.CEC;
+    const int bins = a.PS * a.PS, HW = a.H * a.W;
+    const int slices = gridDim.y, slice = blockIdx.y;
+
+    for (int i = threadIdx.x; i < HW; i += RT) s_plane[i] = 0.0;
+    if (threadIdx.x == 0) s_nbins = 0;
+    __syncthreads();
+    // bins of a RoI that read this score map (PK:111-114, 130): the same for every RoI
+    for (int i = threadIdx.x; i < bins; i += RT) {
+        int gw = (int)floorf((float)(i % a.PS) * (float)a.GS / (float)a.PS);
+        int gh = (int)floorf((float)(i / a.PS) * (float)a.GS / (float)a.PS);
+        gw = min(max(gw, 0), a.GS - 1);
+        gh = min(max(gh, 0), a.GS - 1);
+        if (gh * a.GS + gw == gcell) s_bins[atomicAdd(&s_nbins, 1)] = i;
+    }
+    __syncthreads();
+    const int nbins = s_nbins;
+    if (nbins == 0) return;  // block-uniform; the plane stays zero and gdata is left as it is
+
+    const int per_pass = ROI_CHUNK * slices;
+    for (int base = 0; base < a.R; base += per_pass) {
+        if (threadIdx.x == 0) s_nrois = 0;
+        __syncthreads();
+        for (int k = threadIdx.x; k < ROI_CHUNK; k += RT) {
+            const int n = base + k * slices + slice;
+            if (n < a.R && (int)a.rois[(long)n * 5] == b) s_rois[atomicAdd(&s_nrois, 1)] = n;
+        }
+        __syncthreads();
+        const int items = s_nrois * nbins;
+        for (int item = threadIdx.x; item < items; item += RT) {
+            const int n = s_rois[item / nbins], bin = s_bins[item % nbins];
+            const long oidx = ((long)n * a.OC + ctop) * bins + bin;
+            const float cnt = a.cnt[oidx];
+            if (cnt <= 0.f) continue;  // PK:203-206
+            const float diff_val = a.gout[oidx] / cnt;
+            const RoiBox box = roi_box(a.rois + (long)n * 5, a.scale);
+            const BinGeom g = bin_geom(a, box, n, cls, bin / a.PS, bin % a.PS);
+            float sub_w, sub_h;
+            {
+#pragma clang fp contract(off)
+                sub_h = box.h / (float)a.PS / (float)a.SPP;
+                sub_w = box.w / (float)a.PS / (float)a.SPP;
+            }
+            int pend = -1, pend_sx = 0, pend_sy = 0;
+            float a00 = 0.f, a01 = 0.f, a10 = 0.f, a11 = 0.f;
+            for (int ih = 0; ih < a.SPP; ++ih) {
+                for (int iw = 0; iw < a.SPP; ++iw) {
+                    float w, h;
+                    {
+#pragma clang fp contract(off)
+                        w = g.wstart + (float)iw * sub_w;
+                        h = g.hstart + (float)ih * sub_h;
+                    }
+                    if (!keep_sample(w, h, a.W, a.H)) continue;
+                    const int x0 = (int)floorf(w), x1 = (int)ceilf(w);
+                    const int y0 = (int)floorf(h), y1 = (int)ceilf(h);
+                    const float dx = w - (float)x0, dy = h - (float)y0;
+                    const int p = y0 * a.W + x0, sx = x1 - x0, sy = (y1 - y0) * a.W;
+                    if (p != pend || sx != pend_sx || sy != pend_sy) {
+                        if (pend >= 0) {
+                            lds_add(s_plane + pend, a00);
+                            lds_add(s_plane + pend + pend_sy, a01);
+                            lds_add(s_plane + pend + pend_sx, a10);
+                            lds_add(s_plane + pend + pend_sx + pend_sy, a11);
+                        }
+                        pend = p;
+                        pend_sx = sx;
+                        pend_sy = sy;
+                        a00 = a01 = a10 = a11 = 0.f;
+                    }
+                    a00 += (1.f - dx) * (1.f - dy) * diff_val;
+                    a01 += (1.f - dx) * dy * diff_val;
+                    a10 += dx * (1.f - dy) * diff_val;
+                    a11 += dx * dy * diff_val;
+                }
+            }
+            if (pend >= 0) {
+                lds_add(s_plane + pend, a00);
+                lds_add(s_plane + pend + pend_sy, a01);
+                lds_add(s_plane + pend + pend_sx, a10);
+                lds_add(s_plane + pend + pend_sx + pend_sy, a11);
+            }
+        }
+        __syncthreads();
+    }
+    // one pass over the plane: the only writer of these cells when there is one slice
+    float *gplane = a.gdata + ((long)b * a.C + c) * HW;
+    for (int i = threadIdx.x; i < HW; i += RT) {
+        const float v = (float)s_plane[i];
+        if (v == 0.f) continue;
+        if (slices == 1) gplane[i] += v;
+        else atomicAdd(gplane + i, v);
+    }
+}
+
+int check_roi_geom(const ddcn_roi_geom *g, RoiArgs &a, bool backward)
+{
+    if (!g) return fail(DDCN_ERR_BAD_ARG, "roi geom is NULL");
+    if (g->B <= 0 || g->C <= 0 || g->H <= 0 || g->W <= 0)
+        return fail(DDCN_ERR_SHAPE, "non-positive data size B=%d C=%d H=%d W=%d", g->B, g->C, g->H, g->W);
+    if (g->R < 0) return fail(DDCN_ERR_SHAPE, "negative RoI count %d", g->R);
+    if (g->out_channels <= 0 || g->pooled <= 0 || g->group_size <= 0 || g->part_size <= 0 || g->sample_per_part <= 0)
+        return fail(DDCN_ERR_SHAPE, "non-positive out_channels=%d out_size=%d group_size=%d part_size=%d "
+                    "sample_per_part=%d", g->out_channels, g->pooled, g->group_size, g->part_size, g->sample_per_part);
+    // the kernels read score map (ctop*gs + gh)*gs + gw (PK:130): it has to exist
+    if ((long)g->out_channels * g->group_size * g->group_size != g->C)
+        return fail(DDCN_ERR_SHAPE, "data has %d channels, out_channels*group_size^2 = %ld", g->C,
+                    (long)g->out_channels * g->group_size * g->group_size);
+    int ncls = 1;
+    if (!g->no_trans) {
+        if (g->trans_channels < 2 || g->trans_channels % 2)
+            return fail(DDCN_ERR_SHAPE, "offset has %d channels, need a positive even count", g->trans_channels);
+        ncls = g->trans_channels / 2;  // PK:289
+        if (g->out_channels % ncls)
+            return fail(DDCN_ERR_SHAPE, "out_channels %d not divisible by the %d offset classes", g->out_channels, ncls);
+    }
+    if (!(g->trans_std >= 0.f && g->trans_std <= 1.f))  // deform_pool.py:40
+        return fail(DDCN_ERR_BAD_ARG, "trans_std %g outside [0, 1]", (double)g->trans_std);
+    if ((long)g->H * g->W >= (1L << 31) || (long)g->R * g->out_channels * g->pooled * g->pooled >= (1L << 40))
+        return fail(DDCN_ERR_UNSUPPORTED, "tensor too large");
+    if (backward && (g->pooled * g->pooled > MAX_BINS || g->part_size * g->part_size > MAX_BINS))
+        return fail(DDCN_ERR_UNSUPPORTED, "backward supports out_size, part_size <= 32 (got %d, %d)", g->pooled,
+                    g->part_size);
+    a.B = g->B; a.C = g->C; a.H = g->H; a.W = g->W; a.R = g->R;
+    a.OC = g->out_channels; a.PS = g->pooled; a.GS = g->group_size; a.PART = g->part_size;
+    a.SPP = g->sample_per_part; a.NCLS = ncls; a.CEC = g->out_channels / ncls; a.no_trans = g->no_trans ? 1 : 0;
+    a.scale = g->spatial_scale; a.tstd = g->trans_std;
+    a.chunk = a.CEC;
+    return DDCN_OK;
+}
+
+}  // namespace
+
+int launch_psroi_forward(const float *data, const float *rois, const float *trans, float *out, float *out_count,
+                         const ddcn_roi_geom *g, hipStream_t stream)
+{
+    RoiArgs a = {};
+    if (int rc = check_roi_geom(g, a, false)) return rc;
+    if (a.R == 0) return DDCN_OK;
+    if (!data || !rois || !out || !out_count || (!a.no_trans && !trans))
+        return fail(DDCN_ERR_BAD_ARG, "psroi forward: NULL tensor pointer");
+    a.data = data; a.rois = rois; a.trans = trans; a.out = out; a.out_cnt = out_count;
+    const long total = (long)a.R * a.OC * a.PS * a.PS;
+    const long blocks = (total + RT - 1) / RT;
+    hipLaunchKernelGGL(psroi_forward_kernel, dim3((unsigned)(blocks < (1L << 20) ? blocks : (1L << 20))), dim3(RT), 0,
+                       stream, a);
+    return check_launch("psroi_forward");
+}
+
+int launch_psroi_backward(const float *grad_out, const float *data, const float *rois, const float *trans,
+                          const float *out_count, float *grad_data, float *grad_trans, const ddcn_roi_geom *g,
+                          hipStream_t stream)
+{
+    RoiArgs a = {};
+    if (int rc = check_roi_geom(g, a, true)) return rc;
+    if (a.R == 0) return DDCN_OK;
+    if (!grad_out || !data || !rois || !out_count || !grad_data || (!a.no_trans && (!trans || !grad_trans)))
+        return fail(DDCN_ERR_BAD_ARG, "psroi backward: NULL tensor pointer");
+    if ((long)a.R * a.NCLS >= (1L << 31)) return fail(DDCN_ERR_UNSUPPORTED, "too many RoIs");
+    a.gout = grad_out; a.data = data; a.rois = rois; a.trans = trans; a.cnt = out_count;
+    a.gdata = grad_data; a.gtrans = grad_trans;
+    // Channels of a class are sliced over blockIdx.y until the launch has a few workgroups per CU; each slice still
+    // spans at least one full pass of the workgroup over the bins.
+    const long base_wgs = (long)a.R * a.NCLS;
+    const int bins = a.PS * a.PS;
+    const int min_chunk = (RT + bins - 1) / bins;
+    int slices = (int)((1024 + base_wgs - 1) / base_wgs);
+    int chunk = (a.CEC + slices - 1) / slices;
+    if (chunk < min_chunk) chunk = min_chunk;
+    if (chunk > a.CEC) chunk = a.CEC;
+    a.chunk = chunk;
+    slices = (a.CEC + chunk - 1) / chunk;
+    if (slices > 65535) return fail(DDCN_ERR_UNSUPPORTED, "too many channel slices");
+    // feature gradient: plane-owner kernel when a double plane fits in LDS, else atomics inside the offset kernel
+    const size_t plane_bytes = (size_t)a.H * a.W * sizeof(double);
+    const long planes = (long)a.B * a.C;
+    const bool owner = plane_bytes <= (size_t)PLANE_LDS_MAX && planes < (1L << 31) && !getenv("DDCN_PSROI_ATOMIC");
+    if (owner) {
+        static bool attr_set = false;  // idempotent: a race only repeats the call
+        if (!attr_set) {
+            if (hipFuncSetAttribute((const void *)psroi_backward_plane_kernel,
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, PLANE_LDS_MAX) != hipSuccess)
+                return fail(DDCN_ERR_LAUNCH, "psroi backward: cannot raise the LDS limit to %d bytes", PLANE_LDS_MAX);
+            attr_set = true;
+        }
+        // RoI slices: enough workgroups to fill the chip, but each slice keeps >= 32 RoIs to amortise its plane
+        long rs = (2048 + planes - 1) / planes;
+        const long rs_max = (a.R + 31) / 32;
+        if (rs > rs_max) rs = rs_max;
+        if (rs < 1) rs = 1;
+        if (rs > 64) rs = 64;
+        hipLaunchKernelGGL(psroi_backward_plane_kernel, dim3((unsigned)planes, (unsigned)rs), dim3(RT), plane_bytes,
+                           stream, a);
+        if (int rc = check_launch("psroi_backward_plane")) return rc;
+        if (a.no_trans) return DDCN_OK;
+        hipLaunchKernelGGL(psroi_backward_kernel<false>, dim3((unsigned)base_wgs, (unsigned)slices), dim3(RT), 0,
+                           stream, a);
+    } else {
+        hipLaunchKernelGGL(psroi_backward_kernel<true>, dim3((unsigned)base_wgs, (unsigned)slices), dim3(RT), 0,
+                           stream, a);
+    }
+    return check_launch("psroi_backward");
+}
+
+}  // namespace ddcn

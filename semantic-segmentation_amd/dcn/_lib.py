@@ -20,8 +20,16 @@ class Geom(ctypes.Structure):
                  "groups", "dg", "Ho", "Wo")]
 
 
+class RoiGeom(ctypes.Structure):
+    """struct ddcn_roi_geom (include/ddcn_hip.h)."""
+    _fields_ = [(n, ctypes.c_int) for n in
+                ("B", "C", "H", "W", "R", "out_channels", "pooled", "group_size", "part_size", "sample_per_part",
+                 "trans_channels", "no_trans")] + [("spatial_scale", ctypes.c_float), ("trans_std", ctypes.c_float)]
+
+
 _P = ctypes.c_void_p
 _G = ctypes.POINTER(Geom)
+_RG = ctypes.POINTER(RoiGeom)
 _SZ = ctypes.c_size_t
 
 # name -> argtypes; every entry returns int unless listed in _RESTYPES
@@ -50,6 +58,8 @@ PROTOTYPES = {
     "ddcn_modulated_deform_conv_backward_saved_f32": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _SZ, _G, _P],
     "ddcn_depthaware_conv_forward_f32": [_P, _P, _P, _P, _P, _P, _SZ, _G, _P],
     "ddcn_depthaware_conv_backward_f32": [_P, _P, _P, _P, _P, _P, _P, _P, _SZ, _G, _P],
+    "ddcn_deform_psroi_pool_forward_f32": [_P, _P, _P, _P, _P, _RG, _P],
+    "ddcn_deform_psroi_pool_backward_f32": [_P, _P, _P, _P, _P, _P, _P, _RG, _P],
 }
 _RESTYPES = {
     "ddcn_strerror": ctypes.c_char_p,

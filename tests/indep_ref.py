@@ -77,3 +77,63 @@ def depthaware_conv(x, depth, weight, bias=None, stride=1, padding=0, dilation=1
     kh, kw = weight.shape[2:]
     col = depthaware_columns(x, depth.detach(), kh, kw, stride, padding, dilation)
     return contract(col, weight, bias, groups)
+
+
+def deform_psroi_pool(data, rois, offset, spatial_scale, out_size, out_channels, no_trans, group_size=1,
+                      part_size=None, sample_per_part=4, trans_std=0.0):
+    """Deformable position-sensitive RoI pooling from its definition (Dai et al. 2017, eq. 5-6 with the
+    R-FCN score-map layout): bin (i, j) of RoI n averages `sample_per_part^2` bilinear samples of score map
+    (ctop, gh, gw), taken on a regular sub-grid of the bin shifted by the normalised offset of the bin's part
+    cell times the RoI size.  Samples more than half a pixel outside the map are dropped, the rest are clamped
+    into it.  Autograd supplies every gradient.  RoI corners must be non-negative (round = floor(x + .5)).
+    Returns (output, count)."""
+    part_size = out_size if part_size is None else part_size
+    R = rois.shape[0]
+    _, C, H, W = data.shape
+    classes = 1 if no_trans else offset.shape[1] // 2
+    per_class = out_channels // classes
+    out = []
+    cnt = torch.zeros(R, out_channels, out_size, out_size, dtype=data.dtype)
+    steps = torch.arange(sample_per_part, dtype=data.dtype)
+    for n in range(R):
+        b = int(rois[n, 0])
+        corner = torch.floor(rois[n, 1:] + 0.5)
+        x_lo, y_lo = corner[0] * spatial_scale - 0.5, corner[1] * spatial_scale - 0.5
+        x_hi, y_hi = (corner[2] + 1) * spatial_scale - 0.5, (corner[3] + 1) * spatial_scale - 0.5
+        rw, rh = torch.clamp(x_hi - x_lo, min=0.1), torch.clamp(y_hi - y_lo, min=0.1)
+        bw, bh = rw / out_size, rh / out_size
+        planes = data[b].reshape(out_channels, group_size, group_size, H, W)
+        rows = []
+        for ctop_class in range(classes):
+            maps = planes[ctop_class * per_class:(ctop_class + 1) * per_class]
+            grid_out = torch.zeros(per_class, out_size, out_size, dtype=data.dtype)
+            pieces = []
+            for i in range(out_size):
+                for j in range(out_size):
+                    pi, pj = (i * part_size) // out_size, (j * part_size) // out_size
+                    gi = min((i * group_size) // out_size, group_size - 1)
+                    gj = min((j * group_size) // out_size, group_size - 1)
+                    if no_trans:
+                        tx = ty = torch.zeros((), dtype=data.dtype)
+                    else:
+                        tx = offset[n, 2 * ctop_class, pi, pj] * trans_std
+                        ty = offset[n, 2 * ctop_class + 1, pi, pj] * trans_std
+                    xs = x_lo + j * bw + tx * rw + steps * (bw / sample_per_part)
+                    ys = y_lo + i * bh + ty * rh + steps * (bh / sample_per_part)
+                    yy, xx = torch.meshgrid(ys, xs, indexing="ij")
+                    keep = (xx >= -0.5) & (xx <= W - 0.5) & (yy >= -0.5) & (yy <= H - 0.5)
+                    k = int(keep.sum())
+                    cnt[n, ctop_class * per_class:(ctop_class + 1) * per_class, i, j] = k
+                    if k == 0:
+                        pieces.append(torch.zeros(per_class, dtype=data.dtype))
+                        continue
+                    xx = torch.clamp(xx[keep], 0, W - 1)
+                    yy = torch.clamp(yy[keep], 0, H - 1)
+                    grid = torch.stack((2 * xx / (W - 1) - 1, 2 * yy / (H - 1) - 1), dim=-1).view(1, 1, k, 2)
+                    s = F.grid_sample(maps[:, gi, gj].unsqueeze(0), grid, mode="bilinear", padding_mode="border",
+                                      align_corners=True)
+                    pieces.append(s.view(per_class, k).mean(dim=1))
+            del grid_out
+            rows.append(torch.stack(pieces, dim=1).view(per_class, out_size, out_size))
+        out.append(torch.cat(rows, dim=0))
+    return torch.stack(out, dim=0) if R else torch.zeros(0, out_channels, out_size, out_size, dtype=data.dtype), cnt
