@@ -151,6 +151,20 @@ int ddcn_depthaware_conv_backward_f32(const float *x, const float *depth, const 
                                       const float *grad_out, float *gx, float *gw, float *gb, void *workspace,
                                       size_t workspace_bytes, const ddcn_geom *g, void *stream);
 
+/* ---------------------------------------------------------------- native bf16 forward (inference)
+ * No counterpart in the reference (it dispatches fp64/fp32/fp16 only, K:258): BASELINE config 5, "bf16 activations with
+ * fp32 accumulation".  Every tensor pointer is bfloat16 (torch.bfloat16 data_ptr()): x, weight, bias, offset, mask,
+ * out; coordinates and bilinear weights are computed in fp32, samples are rounded to bf16 columns, the contraction
+ * accumulates in fp32 on v_mfma_f32_32x32x16_bf16 and the result (+ bias) is rounded to bf16 once.  Arithmetic
+ * restated: K:569-632 / K:189-242 (im2col) and H:430-435 / H:232-237 (GEMM).  mask == NULL gives the non-modulated
+ * op, bias may be NULL.  Covered: 3x3 kernels with C, C/groups and C/deformable_groups multiples of 8
+ * (ddcn_bf16_supported() == 0); workspace of ddcn_workspace_bytes_bf16() bytes (the bf16 columns of all N images). */
+size_t ddcn_workspace_bytes_bf16(const ddcn_geom *g);
+int ddcn_bf16_supported(const ddcn_geom *g);
+int ddcn_modulated_deform_conv_forward_bf16(const void *x, const void *weight, const void *bias, const void *offset,
+                                            const void *mask, void *out, void *workspace, size_t workspace_bytes,
+                                            const ddcn_geom *g, void *stream);
+
 /* ---------------------------------------------------------------- deformable PS-RoI pooling
  * Replaces the reference's second extension, `detseg.ops.dcn.deform_pool_cuda`:
  *   PP = detseg/ops/dcn/deform_pool.py

@@ -58,6 +58,11 @@ int launch_gemm_out(const float *weight, const float *col, const float *bias, fl
 int launch_gemm_gcol(const float *weight, const float *gout, float *gcol, const ddcn_geom &g, hipStream_t stream);
 int launch_gemm_gweight(const float *gout, const float *col, float *gw, const ddcn_geom &g, hipStream_t stream);
 
+size_t bf16_workspace_bytes(const ddcn_geom &g);
+int bf16_supported(const ddcn_geom &g);
+int launch_forward_bf16(const void *x, const void *weight, const void *bias, const void *offset, const void *mask,
+                        void *out, void *ws, const ddcn_geom &g, hipStream_t stream);
+
 int launch_psroi_forward(const float *data, const float *rois, const float *trans, float *out, float *out_count,
                          const ddcn_roi_geom *g, hipStream_t stream);
 int launch_psroi_backward(const float *grad_out, const float *data, const float *rois, const float *trans,

@@ -58,6 +58,9 @@ PROTOTYPES = {
     "ddcn_modulated_deform_conv_backward_saved_f32": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _SZ, _G, _P],
     "ddcn_depthaware_conv_forward_f32": [_P, _P, _P, _P, _P, _P, _SZ, _G, _P],
     "ddcn_depthaware_conv_backward_f32": [_P, _P, _P, _P, _P, _P, _P, _P, _SZ, _G, _P],
+    "ddcn_workspace_bytes_bf16": [_G],
+    "ddcn_bf16_supported": [_G],
+    "ddcn_modulated_deform_conv_forward_bf16": [_P, _P, _P, _P, _P, _P, _P, _SZ, _G, _P],
     "ddcn_deform_psroi_pool_forward_f32": [_P, _P, _P, _P, _P, _RG, _P],
     "ddcn_deform_psroi_pool_backward_f32": [_P, _P, _P, _P, _P, _P, _P, _RG, _P],
 }
@@ -66,6 +69,7 @@ _RESTYPES = {
     "ddcn_last_error": ctypes.c_char_p,
     "ddcn_col_ld": _SZ,
     "ddcn_workspace_bytes": _SZ,
+    "ddcn_workspace_bytes_bf16": _SZ,
 }
 
 _lib = None
