@@ -3,18 +3,31 @@
 // bf16 path (deform_conv_cuda_kernel.cu:258 dispatches FLOATING_TYPES_AND_HALF); the arithmetic restated is the
 // same K:569-632 (im2col) and H:430-435 (GEMM) as the fp32 path, with operands rounded to bf16.
 //
-// Two kernels:
-//   im2col_bf16   one lane per (pixel, 8 channels): the 9 taps' corner indices and bilinear weights are computed
-//                 once per tap in fp32 and reused for the 8 channels; the 72 samples leave as nine 16-byte stores.
-//                 Columns layout: col[n][K/8][P][8] -- "k-octets": the 8 consecutive k of one pixel are contiguous,
-//                 consecutive pixels follow.  That is exactly one B fragment of v_mfma_f32_32x32x16_bf16 per 16
-//                 bytes, so the GEMM needs no transpose anywhere, and both this kernel's stores and the GEMM's
-//                 loads are fully coalesced along the pixel axis.
+// Columns layout: col[n][K/8][P][8] -- "k-octets": 8 consecutive k of one pixel are contiguous (16 bytes), consecutive
+// pixels follow.  That is exactly one B fragment of v_mfma_f32_32x32x16_bf16 per 16 bytes, so the GEMM needs no
+// transpose anywhere, and both the im2col stores and the GEMM loads are coalesced along the pixel axis.  The k order
+// inside the path is (channel octet, tap, channel % 8) instead of the reference's (channel, tap): one tap of 8
+// channels is one octet, so a lane stores a finished 16-byte vector per tap.  The weights are repacked to the same
+// order by a tiny kernel at the start of every call (Co*K elements).
+//
+// Kernels:
+//   repack_w      W[Co][C/g][9] -> W'[Co][(C/g)/8][9][8]
+//   im2col_bf16_tile   workgroup = 8x32 tile of output pixels x a group of channels, lane = pixel.  The nine sample
+//                 positions (patch cell, bilinear weights x mask) are computed once per lane; the input patch the
+//                 tile can reach (tile + kernel extent + a margin for the learned offsets) is staged through LDS
+//                 eight channels at a time as [cell][8] bf16, double buffered, so one ds_read_b128 per corner
+//                 brings all eight channels of the octet; cells outside the image hold 0 (= the reference's value
+//                 for out-of-image corners).  Samples whose corners leave the patch are gathered from global memory
+//                 in a second pass.
+//   im2col_bf16   (fallback for geometries whose patch does not fit) one lane per (pixel, 8 channels), corners read
+//                 from global memory.
 //   gemm_bf16     out[Co][P] = W[Co][K] * col: 128x128x64 tiles, 4 waves of 64x64 (2x2 MFMA 32x32x16), operands
 //                 staged global -> registers -> LDS (W rows XOR-swizzled by 16-byte chunk, columns linear),
 //                 next tile's global loads in flight during the MFMAs, bias add and bf16 rounding in the epilogue.
 //                 Workgroups that share a columns tile are consecutive on one XCD (its L2 serves the re-reads).
 #include "ddcn_common.h"
+
+#include <stdlib.h>
 
 namespace ddcn {
 namespace {
@@ -42,9 +55,57 @@ struct Bf16Args {
     int KO;          // k-octets per image: C*9/8
     int Kg, Cog;     // per weight group: K extent, output channels
     int tiles_m, tiles_n;
+    // LDS-tiled im2col
+    int M, RH, RW, RS, CG, tiles, tiles_w;
 };
 
 constexpr int IT = 256;  // im2col threads
+
+// w1*a1 + w2*a2 + w3*a3 + w4*a4 for the two bf16 halves of a register pair, rounded back to a bf16 pair
+__device__ __forceinline__ unsigned blend_pair(unsigned a1, unsigned a2, unsigned a3, unsigned a4, float w1, float w2,
+                                               float w3, float w4)
+{
+    const float lo = w1 * __uint_as_float(a1 << 16) + w2 * __uint_as_float(a2 << 16) + w3 * __uint_as_float(a3 << 16) +
+                     w4 * __uint_as_float(a4 << 16);
+    const float hi = w1 * __uint_as_float(a1 & 0xffff0000u) + w2 * __uint_as_float(a2 & 0xffff0000u) +
+                     w3 * __uint_as_float(a3 & 0xffff0000u) + w4 * __uint_as_float(a4 & 0xffff0000u);
+    return pack2(lo, hi);
+}
+
+// One sample position, 8 consecutive channel planes, corners read from global memory (K:569-632 / K:466-496):
+// -> the octet of bf16 samples (mask folded in).
+__device__ __forceinline__ u32x4 sample_octet_global(const bf16_t *xb, long HW, int H, int W, float h, float w, float m)
+{
+    // K:602-610: zero unless -1 < h < H and -1 < w < W; corners outside the map contribute zero
+    const bool inside = h > -1.f && w > -1.f && h < (float)H && w < (float)W;
+    const float hf = floorf(h), wf = floorf(w);
+    const int hl = (int)hf, wl = (int)wf;
+    const float lh = h - hf, lw = w - wf;
+    const bool t = inside && hl >= 0, b = inside && hl + 1 <= H - 1;
+    const bool l = wl >= 0, r = wl + 1 <= W - 1;
+    const float w1 = (t && l) ? (1.f - lh) * (1.f - lw) * m : 0.f;
+    const float w2 = (t && r) ? (1.f - lh) * lw * m : 0.f;
+    const float w3 = (b && l) ? lh * (1.f - lw) * m : 0.f;
+    const float w4 = (b && r) ? lh * lw * m : 0.f;
+    // a corner outside gets weight 0, a clamped (valid) address, and its value replaced by 0 (silences Inf/NaN)
+    const int hc0 = min(max(hl, 0), H - 1), hc1 = min(max(hl + 1, 0), H - 1);
+    const int wc0 = min(max(wl, 0), W - 1), wc1 = min(max(wl + 1, 0), W - 1);
+    const int i1 = hc0 * W + wc0, i2 = hc0 * W + wc1, i3 = hc1 * W + wc0, i4 = hc1 * W + wc1;
+    float v[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        const bf16_t *pl = xb + c * HW;
+        const float x1 = (t && l) ? bf2f(pl[i1]) : 0.f, x2 = (t && r) ? bf2f(pl[i2]) : 0.f;
+        const float x3 = (b && l) ? bf2f(pl[i3]) : 0.f, x4 = (b && r) ? bf2f(pl[i4]) : 0.f;
+        v[c] = w1 * x1 + w2 * x2 + w3 * x3 + w4 * x4;
+    }
+    u32x4 o;
+    o.x = pack2(v[0], v[1]);
+    o.y = pack2(v[2], v[3]);
+    o.z = pack2(v[4], v[5]);
+    o.w = pack2(v[6], v[7]);
+    return o;
+}
 
 // K:569-632 with bf16 tensors.  grid = (ceil(P/IT), C/8, N)
 template <bool MOD>
@@ -60,10 +121,7 @@ __global__ __launch_bounds__(IT, 4) void im2col_bf16_kernel(const Bf16Args a)
     const bf16_t *offb = a.offset + ((long)n * a.dg + dgi) * 18 * a.P + p;
     const bf16_t *maskb = MOD ? a.mask + ((long)n * a.dg + dgi) * 9 * a.P + p : nullptr;
 
-    // sample (c, k) is element c*9+k of the thread's 72: rounded and packed two per register as it is produced
-    unsigned pk[36];
-#pragma unroll
-    for (int q = 0; q < 36; ++q) pk[q] = 0u;
+    u32x4 *dst = (u32x4 *)a.col + ((long)n * a.KO + (long)co * 9) * a.P + p;
 #pragma unroll
     for (int k = 0; k < 9; ++k) {
         const int i = k / 3, j = k % 3;
@@ -71,41 +129,142 @@ __global__ __launch_bounds__(IT, 4) void im2col_bf16_kernel(const Bf16Args a)
         const float m = MOD ? bf2f(maskb[(long)k * a.P]) : 1.f;
         const float h = (float)(ho * a.sh - a.ph + i * a.dh) + oh;
         const float w = (float)(wo * a.sw - a.pw + j * a.dw) + ow;
-        // K:602-610: zero unless -1 < h < H and -1 < w < W; corners outside the map contribute zero (K:466-496)
-        const bool inside = h > -1.f && w > -1.f && h < (float)a.H && w < (float)a.W;
-        const float hf = floorf(h), wf = floorf(w);
-        const int hl = (int)hf, wl = (int)wf;
-        const float lh = h - hf, lw = w - wf;
-        const bool t = inside && hl >= 0, b = inside && hl + 1 <= a.H - 1;
-        const bool l = wl >= 0, r = wl + 1 <= a.W - 1;
-        // fold the mask into the four weights; a corner outside gets weight 0 and a clamped (valid) address
-        const float w1 = (t && l) ? (1.f - lh) * (1.f - lw) * m : 0.f;
-        const float w2 = (t && r) ? (1.f - lh) * lw * m : 0.f;
-        const float w3 = (b && l) ? lh * (1.f - lw) * m : 0.f;
-        const float w4 = (b && r) ? lh * lw * m : 0.f;
-        const int hc0 = min(max(hl, 0), a.H - 1), hc1 = min(max(hl + 1, 0), a.H - 1);
-        const int wc0 = min(max(wl, 0), a.W - 1), wc1 = min(max(wl + 1, 0), a.W - 1);
-        const int i1 = hc0 * a.W + wc0, i2 = hc0 * a.W + wc1, i3 = hc1 * a.W + wc0, i4 = hc1 * a.W + wc1;
+        dst[(long)k * a.P] = sample_octet_global(xb, HW, a.H, a.W, h, w, m);
+    }
+}
+
+// One weight row element per thread: W'[row][oct][tap][e] = W[row][(oct*8+e)*9 + tap]
+__global__ __launch_bounds__(256) void repack_w_kernel(const bf16_t *w, bf16_t *wp, long total, int K)
+{
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const long row = i / K;
+    const int kk = (int)(i - row * K);
+    const int e = kk & 7, tap = (kk >> 3) % 9, oct = (kk >> 3) / 9;
+    wp[i] = w[row * K + (oct * 8 + e) * 9 + tap];
+}
+
+// ---------------------------------------------------------------- LDS-tiled im2col
+constexpr int TH = 8, TW = 32;
+
+// grid = (tiles * cgroups, 1, N); dynamic LDS = 2 buffers of RS cells x 16 bytes
+template <bool MOD, int NCELL>
+__global__ __launch_bounds__(IT, 2) void im2col_bf16_tile_kernel(const Bf16Args a)
+{
+    extern __shared__ u32x4 patch[];
+    const int t = threadIdx.x;
+    const int tile = blockIdx.x % a.tiles, cgi = blockIdx.x / a.tiles, n = blockIdx.z;
+    const int tyi = tile / a.tiles_w, txi = tile - tyi * a.tiles_w;
+    const int ty = t / TW, tx = t - ty * TW;
+    const int ho = tyi * TH + ty, wo = txi * TW + tx;
+    const bool live = ho < a.Ho && wo < a.Wo;
+    const int rh0 = tyi * TH * a.sh - a.ph - a.M, rw0 = txi * TW * a.sw - a.pw - a.M;  // image coords of patch cell 0
+    const int c_begin = cgi * a.CG;
+    const int dgi = c_begin / a.cpg;
+    const int HW = a.H * a.W;
+    const int p = live ? ho * a.Wo + wo : 0;
+    const bf16_t *xb = a.x + ((long)n * a.C + c_begin) * HW;
+
+    // offsets and masks go in flight first
+    float roh[9], row_[9], rm[9];
+    {
+        const bf16_t *offb = a.offset + ((long)n * a.dg + dgi) * 18 * a.P + p;
+        const bf16_t *maskb = MOD ? a.mask + ((long)n * a.dg + dgi) * 9 * a.P + p : nullptr;
 #pragma unroll
-        for (int c = 0; c < 8; ++c) {
-            const bf16_t *pl = xb + c * HW;
-            // a corner outside the map must also silence an Inf/NaN at its clamped address: select, then multiply
-            const float x1 = (t && l) ? bf2f(pl[i1]) : 0.f, x2 = (t && r) ? bf2f(pl[i2]) : 0.f;
-            const float x3 = (b && l) ? bf2f(pl[i3]) : 0.f, x4 = (b && r) ? bf2f(pl[i4]) : 0.f;
-            const unsigned v = f2bf(w1 * x1 + w2 * x2 + w3 * x3 + w4 * x4);
-            const int e = c * 9 + k;
-            pk[e >> 1] |= (e & 1) ? v << 16 : v;   // pk starts at zero, each half is written once
+        for (int k = 0; k < 9; ++k) {
+            roh[k] = live ? bf2f(offb[(long)(2 * k) * a.P]) : 0.f;
+            row_[k] = live ? bf2f(offb[(long)(2 * k + 1) * a.P]) : 0.f;
+            rm[k] = (MOD && live) ? bf2f(maskb[(long)k * a.P]) : 1.f;
         }
     }
-    u32x4 *dst = (u32x4 *)(a.col + (((long)n * a.KO + (long)co * 9) * a.P + p) * 8);
+    // staging: cell i = t + 256 j of the patch -> element offset inside one channel plane, -1 outside the image
+    int soff[NCELL];
 #pragma unroll
-    for (int j = 0; j < 9; ++j) {
-        u32x4 v;
-        v.x = pk[4 * j + 0];
-        v.y = pk[4 * j + 1];
-        v.z = pk[4 * j + 2];
-        v.w = pk[4 * j + 3];
-        dst[(long)j * a.P] = v;
+    for (int j = 0; j < NCELL; ++j) {
+        const int i = t + IT * j;
+        const int rr = i / a.RW, rc = i - rr * a.RW;
+        const int y = rh0 + rr, xx = rw0 + rc;
+        soff[j] = (i < a.RS && y >= 0 && y < a.H && xx >= 0 && xx < a.W) ? y * a.W + xx : -1;
+    }
+    // per tap: patch cell of the (hl, wl) corner (-1 escapee, -2 sample is zero), weights with the mask folded in
+    int cell[9];
+    float w1[9], w2[9], w3[9], w4[9], sh_[9], sw_[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+        const int i = k / 3, j = k - 3 * i;
+        const float h = (float)(ho * a.sh - a.ph + i * a.dh) + roh[k];
+        const float w = (float)(wo * a.sw - a.pw + j * a.dw) + row_[k];
+        sh_[k] = h;
+        sw_[k] = w;
+        const float hf = floorf(h), wf = floorf(w);
+        const float lh = h - hf, lw = w - wf;
+        const float m = rm[k];
+        w1[k] = (1.f - lh) * (1.f - lw) * m; w2[k] = (1.f - lh) * lw * m;
+        w3[k] = lh * (1.f - lw) * m;         w4[k] = lh * lw * m;
+        int c = -2;
+        if (live && h > -1.f && w > -1.f && h < (float)a.H && w < (float)a.W) {  // K:602-610
+            const int rr = (int)hf - rh0, rc = (int)wf - rw0;
+            c = (rr >= 0 && rr + 1 < a.RH && rc >= 0 && rc + 1 < a.RW) ? rr * a.RW + rc : -1;
+        }
+        cell[k] = c;
+    }
+
+    u32x4 *buf0 = patch, *buf1 = patch + a.RS;
+    u32x4 stg[NCELL];
+    auto stage_load = [&](int c0) {   // c0 relative to c_begin
+#pragma unroll
+        for (int j = 0; j < NCELL; ++j) {
+            unsigned short v[8];
+#pragma unroll
+            for (int c = 0; c < 8; ++c) v[c] = soff[j] >= 0 ? xb[(long)(c0 + c) * HW + soff[j]] : (unsigned short)0;
+            stg[j].x = v[0] | ((unsigned)v[1] << 16);
+            stg[j].y = v[2] | ((unsigned)v[3] << 16);
+            stg[j].z = v[4] | ((unsigned)v[5] << 16);
+            stg[j].w = v[6] | ((unsigned)v[7] << 16);
+        }
+    };
+    auto stage_store = [&](u32x4 *buf) {
+#pragma unroll
+        for (int j = 0; j < NCELL; ++j)
+            if (t + IT * j < a.RS) buf[t + IT * j] = stg[j];
+    };
+
+    stage_load(0);
+    stage_store(buf0);
+    __syncthreads();
+    const int nocts = a.CG / 8;
+    u32x4 *colp = (u32x4 *)a.col + ((long)n * a.KO + (long)(c_begin / 8) * 9) * a.P + p;
+    for (int oc = 0; oc < nocts; ++oc) {
+        const u32x4 *cur = (oc & 1) ? buf1 : buf0;
+        u32x4 *nxt = (oc & 1) ? buf0 : buf1;
+        if (oc + 1 < nocts) stage_load((oc + 1) * 8);
+        if (live) {
+#pragma unroll
+            for (int k = 0; k < 9; ++k) {
+                if (cell[k] == -1) continue;   // escapee: second pass
+                const int ci = cell[k] < 0 ? 0 : cell[k];
+                const u32x4 a1 = cur[ci], a2 = cur[ci + 1], a3 = cur[ci + a.RW], a4 = cur[ci + a.RW + 1];
+                const float q1 = cell[k] < 0 ? 0.f : w1[k], q2 = cell[k] < 0 ? 0.f : w2[k];
+                const float q3 = cell[k] < 0 ? 0.f : w3[k], q4 = cell[k] < 0 ? 0.f : w4[k];
+                u32x4 o;
+                o.x = blend_pair(a1.x, a2.x, a3.x, a4.x, q1, q2, q3, q4);
+                o.y = blend_pair(a1.y, a2.y, a3.y, a4.y, q1, q2, q3, q4);
+                o.z = blend_pair(a1.z, a2.z, a3.z, a4.z, q1, q2, q3, q4);
+                o.w = blend_pair(a1.w, a2.w, a3.w, a4.w, q1, q2, q3, q4);
+                colp[((long)oc * 9 + k) * a.P] = o;
+            }
+        }
+        if (oc + 1 < nocts) stage_store(nxt);
+        __syncthreads();
+    }
+    // second pass: samples whose corners leave the staged patch, from global memory with the reference's guards
+    if (live) {
+#pragma unroll
+        for (int k = 0; k < 9; ++k) {
+            if (cell[k] != -1) continue;
+            for (int oc = 0; oc < nocts; ++oc)
+                colp[((long)oc * 9 + k) * a.P] = sample_octet_global(xb + (long)oc * 8 * HW, HW, a.H, a.W, sh_[k], sw_[k], rm[k]);
+        }
     }
 }
 
@@ -224,9 +383,15 @@ __global__ __launch_bounds__(GT) void gemm_bf16_kernel(const Bf16Args a)
 
 }  // namespace
 
+static size_t col_bytes(const ddcn_geom &g)
+{
+    return round_up((size_t)g.N * g.C * 9 * g.Ho * g.Wo * 2, 256);
+}
+
+// bf16 columns of all N images, then the repacked weights
 size_t bf16_workspace_bytes(const ddcn_geom &g)
 {
-    return (size_t)g.N * g.C * g.kh * g.kw * g.Ho * g.Wo * 2;
+    return col_bytes(g) + (size_t)g.Co * (g.C / g.groups) * 9 * 2;
 }
 
 // 0 when the native bf16 path covers the geometry, else DDCN_ERR_UNSUPPORTED with the reason
@@ -238,9 +403,44 @@ int bf16_supported(const ddcn_geom &g)
                     "(C=%d dg=%d groups=%d)", g.C, g.dg, g.groups);
     const long P = (long)g.Ho * g.Wo;
     if (P >= (1L << 31) / 16 || (long)g.H * g.W >= (1L << 31) || (long)g.N * g.groups > 65535 || g.C / 8 > 65535 ||
-        g.N > 65535)
+        g.N > 65535 || (long)g.Co * (g.C / g.groups) * 9 >= (1L << 31))
         return fail(DDCN_ERR_UNSUPPORTED, "bf16 path: tensor too large");
     return DDCN_OK;
+}
+
+// Chooses margin, patch and channel group of the LDS-tiled im2col; false: use the direct kernel.
+static bool plan_bf16_tile(Bf16Args &a, const ddcn_geom &g)
+{
+    const char *e = getenv("DDCN_BF16_TILE");
+    if (e && atoi(e) == 0) return false;
+    const char *em = getenv("DDCN_BF16_MARGIN");
+    int M = em ? atoi(em) : 6;
+    if (M < 0) M = 0;
+    for (;; --M) {
+        a.RH = (TH - 1) * g.sh + 2 * g.dh + 2 * M + 2;
+        a.RW = (TW - 1) * g.sw + 2 * g.dw + 2 * M + 2;
+        a.RS = a.RH * a.RW;
+        if (a.RS <= 8 * IT) break;   // 2 buffers x 2048 cells x 16 B = 64 KB of LDS
+        if (M <= 2) return false;
+    }
+    a.M = M;
+    a.tiles_w = (g.Wo + TW - 1) / TW;
+    a.tiles = a.tiles_w * ((g.Ho + TH - 1) / TH);
+    // channel group: inside one deformable group; split further while the launch is short of workgroups
+    int CG = g.C / g.dg;
+    while (CG % 16 == 0 && (long)a.tiles * g.N * (g.C / CG) < 1024) CG /= 2;
+    a.CG = CG;
+    return (long)a.tiles * (g.C / CG) < (1L << 31);
+}
+
+template <bool MOD>
+static void run_bf16_tile(const Bf16Args &a, const dim3 &grid, hipStream_t stream)
+{
+    const size_t lds = (size_t)2 * a.RS * 16;
+    const int ncell = (a.RS + IT - 1) / IT;
+    if (ncell <= 4) hipLaunchKernelGGL((im2col_bf16_tile_kernel<MOD, 4>), grid, dim3(IT), lds, stream, a);
+    else if (ncell <= 6) hipLaunchKernelGGL((im2col_bf16_tile_kernel<MOD, 6>), grid, dim3(IT), lds, stream, a);
+    else hipLaunchKernelGGL((im2col_bf16_tile_kernel<MOD, 8>), grid, dim3(IT), lds, stream, a);
 }
 
 int launch_forward_bf16(const void *x, const void *weight, const void *bias, const void *offset, const void *mask,
@@ -249,7 +449,7 @@ int launch_forward_bf16(const void *x, const void *weight, const void *bias, con
     if (int rc = bf16_supported(g)) return rc;
     Bf16Args a = {};
     a.x = (const bf16_t *)x; a.offset = (const bf16_t *)offset; a.mask = (const bf16_t *)mask;
-    a.weight = (const bf16_t *)weight; a.bias = (const bf16_t *)bias;
+    a.bias = (const bf16_t *)bias;
     a.col = (bf16_t *)ws; a.out = (bf16_t *)out;
     a.N = g.N; a.C = g.C; a.H = g.H; a.W = g.W; a.Co = g.Co; a.Ho = g.Ho; a.Wo = g.Wo; a.P = g.Ho * g.Wo;
     a.sh = g.sh; a.sw = g.sw; a.ph = g.ph; a.pw = g.pw; a.dh = g.dh; a.dw = g.dw;
@@ -260,9 +460,23 @@ int launch_forward_bf16(const void *x, const void *weight, const void *bias, con
     a.tiles_m = (a.Cog + BM - 1) / BM;
     a.tiles_n = (a.P + BN - 1) / BN;
 
-    const dim3 ig((unsigned)((a.P + IT - 1) / IT), (unsigned)(g.C / 8), (unsigned)g.N);
-    if (mask) hipLaunchKernelGGL(im2col_bf16_kernel<true>, ig, dim3(IT), 0, stream, a);
-    else hipLaunchKernelGGL(im2col_bf16_kernel<false>, ig, dim3(IT), 0, stream, a);
+    // weights into the path's k order
+    bf16_t *wp = (bf16_t *)((char *)ws + col_bytes(g));
+    const long wtotal = (long)g.Co * a.Kg;
+    hipLaunchKernelGGL(repack_w_kernel, dim3((unsigned)((wtotal + 255) / 256)), dim3(256), 0, stream,
+                       (const bf16_t *)weight, wp, wtotal, a.Kg);
+    if (int rc = check_launch("repack_w")) return rc;
+    a.weight = wp;
+
+    if (plan_bf16_tile(a, g)) {
+        const dim3 grid((unsigned)(a.tiles * (g.C / a.CG)), 1, (unsigned)g.N);
+        if (mask) run_bf16_tile<true>(a, grid, stream);
+        else run_bf16_tile<false>(a, grid, stream);
+    } else {
+        const dim3 ig((unsigned)((a.P + IT - 1) / IT), (unsigned)(g.C / 8), (unsigned)g.N);
+        if (mask) hipLaunchKernelGGL(im2col_bf16_kernel<true>, ig, dim3(IT), 0, stream, a);
+        else hipLaunchKernelGGL(im2col_bf16_kernel<false>, ig, dim3(IT), 0, stream, a);
+    }
     if (int rc = check_launch("im2col_bf16")) return rc;
     const long tiles = (long)a.tiles_m * a.tiles_n;
     if (tiles >= (1L << 31)) return fail(DDCN_ERR_UNSUPPORTED, "bf16 path: too many GEMM tiles");
