@@ -45,7 +45,14 @@ __device__ __forceinline__ unsigned f2bf(float f)
     if ((u & 0x7fffffffu) > 0x7f800000u) return (u >> 16) | 0x40u;
     return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
 }
-__device__ __forceinline__ unsigned pack2(float lo, float hi) { return f2bf(lo) | (f2bf(hi) << 16); }
+// two floats -> bf16 pair (round to nearest even): one v_cvt_pk_bf16_f32 on gfx950
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+__device__ __forceinline__ unsigned pack2(float lo, float hi)
+{
+    const f32x2 v = {lo, hi};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
+}
 
 struct Bf16Args {
     const bf16_t *x, *offset, *mask, *weight, *bias;
@@ -57,6 +64,7 @@ struct Bf16Args {
     int tiles_m, tiles_n;
     // LDS-tiled im2col
     int M, RH, RW, RS, CG, tiles, tiles_w;
+    int pair, rw_shift;   // pair staging: patch starts rw_shift columns further left so that it starts on an even column
 };
 
 constexpr int IT = 256;  // im2col threads
@@ -148,7 +156,8 @@ __global__ __launch_bounds__(256) void repack_w_kernel(const bf16_t *w, bf16_t *
 constexpr int TH = 8, TW = 32;
 
 // grid = (tiles * cgroups, 1, N); dynamic LDS = 2 buffers of RS cells x 16 bytes
-template <bool MOD, int NCELL>
+// PAIR: the patch is staged two cells per 4-byte load (W even, patch columns start on an even image column)
+template <bool MOD, int NCELL, bool PAIR>
 __global__ __launch_bounds__(IT, 2) void im2col_bf16_tile_kernel(const Bf16Args a)
 {
     extern __shared__ u32x4 patch[];
@@ -158,7 +167,8 @@ __global__ __launch_bounds__(IT, 2) void im2col_bf16_tile_kernel(const Bf16Args 
     const int ty = t / TW, tx = t - ty * TW;
     const int ho = tyi * TH + ty, wo = txi * TW + tx;
     const bool live = ho < a.Ho && wo < a.Wo;
-    const int rh0 = tyi * TH * a.sh - a.ph - a.M, rw0 = txi * TW * a.sw - a.pw - a.M;  // image coords of patch cell 0
+    // image coords of patch cell 0
+    const int rh0 = tyi * TH * a.sh - a.ph - a.M, rw0 = txi * TW * a.sw - a.pw - a.M - a.rw_shift;
     const int c_begin = cgi * a.CG;
     const int dgi = c_begin / a.cpg;
     const int HW = a.H * a.W;
@@ -178,24 +188,24 @@ __global__ __launch_bounds__(IT, 2) void im2col_bf16_tile_kernel(const Bf16Args 
         }
     }
     // staging: cell i = t + 256 j of the patch -> element offset inside one channel plane, -1 outside the image
-    int soff[NCELL];
+    // (PAIR: unit i is the cell pair 2i, 2i+1; xx is even and W is even, so a pair is inside or outside as a whole)
+    constexpr int NUNIT = PAIR ? NCELL / 2 : NCELL;
+    int soff[NUNIT];
 #pragma unroll
-    for (int j = 0; j < NCELL; ++j) {
-        const int i = t + IT * j;
+    for (int j = 0; j < NUNIT; ++j) {
+        const int i = (t + IT * j) * (PAIR ? 2 : 1);
         const int rr = i / a.RW, rc = i - rr * a.RW;
         const int y = rh0 + rr, xx = rw0 + rc;
         soff[j] = (i < a.RS && y >= 0 && y < a.H && xx >= 0 && xx < a.W) ? y * a.W + xx : -1;
     }
     // per tap: patch cell of the (hl, wl) corner (-1 escapee, -2 sample is zero), weights with the mask folded in
     int cell[9];
-    float w1[9], w2[9], w3[9], w4[9], sh_[9], sw_[9];
+    float w1[9], w2[9], w3[9], w4[9];
 #pragma unroll
     for (int k = 0; k < 9; ++k) {
         const int i = k / 3, j = k - 3 * i;
         const float h = (float)(ho * a.sh - a.ph + i * a.dh) + roh[k];
         const float w = (float)(wo * a.sw - a.pw + j * a.dw) + row_[k];
-        sh_[k] = h;
-        sw_[k] = w;
         const float hf = floorf(h), wf = floorf(w);
         const float lh = h - hf, lw = w - wf;
         const float m = rm[k];
@@ -212,21 +222,50 @@ __global__ __launch_bounds__(IT, 2) void im2col_bf16_tile_kernel(const Bf16Args 
     u32x4 *buf0 = patch, *buf1 = patch + a.RS;
     u32x4 stg[NCELL];
     auto stage_load = [&](int c0) {   // c0 relative to c_begin
+        if constexpr (PAIR) {
 #pragma unroll
-        for (int j = 0; j < NCELL; ++j) {
-            unsigned short v[8];
+            for (int j = 0; j < NUNIT; ++j) {
+                unsigned d[8];
 #pragma unroll
-            for (int c = 0; c < 8; ++c) v[c] = soff[j] >= 0 ? xb[(long)(c0 + c) * HW + soff[j]] : (unsigned short)0;
-            stg[j].x = v[0] | ((unsigned)v[1] << 16);
-            stg[j].y = v[2] | ((unsigned)v[3] << 16);
-            stg[j].z = v[4] | ((unsigned)v[5] << 16);
-            stg[j].w = v[6] | ((unsigned)v[7] << 16);
+                for (int c = 0; c < 8; ++c)
+                    d[c] = soff[j] >= 0 ? *(const unsigned *)(xb + (long)(c0 + c) * HW + soff[j]) : 0u;
+                stg[2 * j].x = (d[0] & 0xffffu) | (d[1] << 16);
+                stg[2 * j].y = (d[2] & 0xffffu) | (d[3] << 16);
+                stg[2 * j].z = (d[4] & 0xffffu) | (d[5] << 16);
+                stg[2 * j].w = (d[6] & 0xffffu) | (d[7] << 16);
+                stg[2 * j + 1].x = (d[0] >> 16) | (d[1] & 0xffff0000u);
+                stg[2 * j + 1].y = (d[2] >> 16) | (d[3] & 0xffff0000u);
+                stg[2 * j + 1].z = (d[4] >> 16) | (d[5] & 0xffff0000u);
+                stg[2 * j + 1].w = (d[6] >> 16) | (d[7] & 0xffff0000u);
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < NCELL; ++j) {
+                unsigned short v[8];
+#pragma unroll
+                for (int c = 0; c < 8; ++c) v[c] = soff[j] >= 0 ? xb[(long)(c0 + c) * HW + soff[j]] : (unsigned short)0;
+                stg[j].x = v[0] | ((unsigned)v[1] << 16);
+                stg[j].y = v[2] | ((unsigned)v[3] << 16);
+                stg[j].z = v[4] | ((unsigned)v[5] << 16);
+                stg[j].w = v[6] | ((unsigned)v[7] << 16);
+            }
         }
     };
     auto stage_store = [&](u32x4 *buf) {
+        if constexpr (PAIR) {
 #pragma unroll
-        for (int j = 0; j < NCELL; ++j)
-            if (t + IT * j < a.RS) buf[t + IT * j] = stg[j];
+            for (int j = 0; j < NUNIT; ++j) {
+                const int i = (t + IT * j) * 2;
+                if (i < a.RS) {
+                    buf[i] = stg[2 * j];
+                    buf[i + 1] = stg[2 * j + 1];
+                }
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < NCELL; ++j)
+                if (t + IT * j < a.RS) buf[t + IT * j] = stg[j];
+        }
     };
 
     stage_load(0);
@@ -262,8 +301,13 @@ __global__ __launch_bounds__(IT, 2) void im2col_bf16_tile_kernel(const Bf16Args 
 #pragma unroll
         for (int k = 0; k < 9; ++k) {
             if (cell[k] != -1) continue;
+            // rare: reload the offsets rather than keep 27 registers alive through the main loop
+            const bf16_t *offb = a.offset + ((long)n * a.dg + dgi) * 18 * a.P + p;
+            const float h = (float)(ho * a.sh - a.ph + (k / 3) * a.dh) + bf2f(offb[(long)(2 * k) * a.P]);
+            const float w = (float)(wo * a.sw - a.pw + (k % 3) * a.dw) + bf2f(offb[(long)(2 * k + 1) * a.P]);
+            const float m = MOD ? bf2f(a.mask[(((long)n * a.dg + dgi) * 9 + k) * a.P + p]) : 1.f;
             for (int oc = 0; oc < nocts; ++oc)
-                colp[((long)oc * 9 + k) * a.P] = sample_octet_global(xb + (long)oc * 8 * HW, HW, a.H, a.W, sh_[k], sw_[k], rm[k]);
+                colp[((long)oc * 9 + k) * a.P] = sample_octet_global(xb + (long)oc * 8 * HW, HW, a.H, a.W, h, w, m);
         }
     }
 }
@@ -416,9 +460,14 @@ static bool plan_bf16_tile(Bf16Args &a, const ddcn_geom &g)
     const char *em = getenv("DDCN_BF16_MARGIN");
     int M = em ? atoi(em) : 6;
     if (M < 0) M = 0;
+    // 4-byte staging loads need even rows, even planes and an aligned base
+    const char *ep = getenv("DDCN_BF16_PAIR");
+    a.pair = (g.W % 2 == 0 && ((uintptr_t)a.x & 3) == 0 && !(ep && atoi(ep) == 0)) ? 1 : 0;
     for (;; --M) {
+        a.rw_shift = (a.pair && ((g.pw + M) & 1)) ? 1 : 0;   // TW * sw is even: the parity is the same for every tile
         a.RH = (TH - 1) * g.sh + 2 * g.dh + 2 * M + 2;
-        a.RW = (TW - 1) * g.sw + 2 * g.dw + 2 * M + 2;
+        a.RW = (TW - 1) * g.sw + 2 * g.dw + 2 * M + 2 + a.rw_shift;
+        if (a.pair) a.RW += a.RW & 1;
         a.RS = a.RH * a.RW;
         if (a.RS <= 8 * IT) break;   // 2 buffers x 2048 cells x 16 B = 64 KB of LDS
         if (M <= 2) return false;
@@ -438,9 +487,15 @@ static void run_bf16_tile(const Bf16Args &a, const dim3 &grid, hipStream_t strea
 {
     const size_t lds = (size_t)2 * a.RS * 16;
     const int ncell = (a.RS + IT - 1) / IT;
-    if (ncell <= 4) hipLaunchKernelGGL((im2col_bf16_tile_kernel<MOD, 4>), grid, dim3(IT), lds, stream, a);
-    else if (ncell <= 6) hipLaunchKernelGGL((im2col_bf16_tile_kernel<MOD, 6>), grid, dim3(IT), lds, stream, a);
-    else hipLaunchKernelGGL((im2col_bf16_tile_kernel<MOD, 8>), grid, dim3(IT), lds, stream, a);
+    if (a.pair) {
+        if (ncell <= 4) hipLaunchKernelGGL((im2col_bf16_tile_kernel<MOD, 4, true>), grid, dim3(IT), lds, stream, a);
+        else if (ncell <= 6) hipLaunchKernelGGL((im2col_bf16_tile_kernel<MOD, 6, true>), grid, dim3(IT), lds, stream, a);
+        else hipLaunchKernelGGL((im2col_bf16_tile_kernel<MOD, 8, true>), grid, dim3(IT), lds, stream, a);
+    } else {
+        if (ncell <= 4) hipLaunchKernelGGL((im2col_bf16_tile_kernel<MOD, 4, false>), grid, dim3(IT), lds, stream, a);
+        else if (ncell <= 6) hipLaunchKernelGGL((im2col_bf16_tile_kernel<MOD, 6, false>), grid, dim3(IT), lds, stream, a);
+        else hipLaunchKernelGGL((im2col_bf16_tile_kernel<MOD, 8, false>), grid, dim3(IT), lds, stream, a);
+    }
 }
 
 int launch_forward_bf16(const void *x, const void *weight, const void *bias, const void *offset, const void *mask,
