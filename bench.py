@@ -5,7 +5,10 @@ A step = one forward + one backward of the modulated DDCN op (the main op of the
 DepthDeformConvPack, detseg/ops/dcn/deform_conv.py:457-463) through the autograd.Function boundary, on
 synthetic inputs already resident in HBM.  Workload = BASELINE.json configs[0] layer: ResNet res5 shape,
 N=2 per GPU, C=512->512, 97x97, 3x3, stride 1, pad=dilation=4, groups=1, deformable_groups=1, fp32.
-(configs[1], the whole DDCN-ResNet50 model, needs the model callers -- SURVEY.md 8(f3), "next".)
+`--workload r50` / `--workload r101` run the whole models of BASELINE configs[1] / configs[2] instead (DDCN-ResNet50
+NYUv2 480x640 batch 4; DDCN-ResNet101 769^2 batch 8 -- SURVEY.md 8(f3)/(f2) callers): a step is then forward +
+backward + gradient all-reduce (N > 1) + SGD update, and the line reports train images/s.  The default stays the
+layer: it is the workload the op metric (GB/s, %MFMA) and the per-kernel rooflines are defined on.
 
 value = algorithmic gather/scatter bytes of the reference algorithm per step (SURVEY.md 8(d):
 775.8 MB/image = 2*B_im2col + B_col2im + B_coord) * images / time.  The op is MFMA-bound overall, so the
@@ -146,6 +149,69 @@ def cpu_baseline(w, threads):
                 tflops=round(a["f_total"] / dt / 1e12, 4))
 
 
+MODEL_WORKLOADS = {
+    # BASELINE configs[1]: configs/nyuv2/danet_r50_depthdeform.py (4 images per GPU, 40 classes, plain BN)
+    "r50": dict(depth=50, deep_base=False, batch=4, h=480, w=640, classes=40,
+                name="BASELINE configs[1]: DDCN-ResNet50 + DANet head, NYUv2 480x640 RGB + HHA"),
+    # BASELINE configs[2]: configs/sunrgbd/danet_r101_depthdeform.py with deep_base, 19 classes, 769^2 crops
+    "r101": dict(depth=101, deep_base=True, batch=8, h=769, w=769, classes=19,
+                 name="BASELINE configs[2]: DDCN-ResNet101 (deep stem) + DANet head, Cityscapes-style 769x769 crop"),
+}
+
+
+def model_workload(args, world, rank, dev):
+    """Training step of a whole DDCN model: forward, loss, backward, bucketed gradient
+    all-reduce over RCCL when world > 1, SGD(momentum, wd) update with the poly schedule."""
+    callers = importlib.import_module("semantic-segmentation_amd.callers")
+    cfg = MODEL_WORKLOADS[args.workload]
+    n = args.batch if args.batch != 2 else cfg["batch"]     # --batch overrides the config's images per GPU
+    torch.manual_seed(0)                                    # same initial weights on every rank
+    backbone = callers.ResNet(cfg["depth"], strides=(1, 2, 1, 1), dilations=(1, 1, 2, 4),
+                              dcn=dict(dcn_type="depthdeform"), stage_with_dcn=(False, True, True, True),
+                              norm_eval=False, deep_base=cfg["deep_base"])
+    model = callers.DANet(backbone, callers.DANetHead(2048, cfg["classes"]), callers.PointNet()).to(dev).train()
+    opt = callers.build_optimizer(model)
+    g = torch.Generator().manual_seed(1234 + rank)
+    label = torch.randint(0, cfg["classes"], (n, cfg["h"], cfg["w"]), generator=g)
+    label[torch.rand(n, cfg["h"], cfg["w"], generator=g) < 0.05] = 255      # 5 % ignored (configs: ignore_index=255)
+    batch = dict(img=torch.randn(n, 3, cfg["h"], cfg["w"], generator=g).to(dev),
+                 HHA=torch.randn(n, 3, cfg["h"], cfg["w"], generator=g).to(dev), gt_label=label.to(dev))
+    total = args.warmup + args.steps
+    it = 0
+    for _ in range(args.warmup):
+        callers.train_step(model, opt, batch, it, total)
+        it += 1
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = callers.train_step(model, opt, batch, it, total)
+        it += 1
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+    if rank == 0:
+        print(json.dumps({
+            "metric": "train images/sec", "value": round(n * world * args.steps / dt, 3), "unit": "images/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": cfg["name"] + ", %d images/GPU, fwd+bwd+SGD step, random init" % n,
+                       "images_per_gpu": n, "parallelism": "dp%d" % world,
+                       "params_M": round(sum(p.numel() for p in model.parameters()) / 1e6, 2)},
+            "final_loss": round(float(loss), 4),
+            "peak_mem_GB": round(torch.cuda.max_memory_allocated() / 2 ** 30, 2),
+        }), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -155,6 +221,7 @@ def main():
     ap.add_argument("--channels", type=int, default=512)
     ap.add_argument("--size", type=int, default=97)
     ap.add_argument("--dilation", type=int, default=4)
+    ap.add_argument("--workload", choices=("layer", "r50", "r101"), default="layer")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     args = ap.parse_args()
@@ -170,6 +237,12 @@ def main():
         dist.init_process_group("nccl", device_id=dev)   # "nccl" is RCCL on ROCm
     pkg = importlib.import_module("semantic-segmentation_amd")
     dist_utils = importlib.import_module("semantic-segmentation_amd.dist_utils")
+
+    if args.workload != "layer":
+        model_workload(args, world, rank, dev)
+        if world > 1:
+            dist.destroy_process_group()
+        return
 
     w = workload(args)
     x, weight, offset, mask, gout = make_inputs(w, dev, seed=1234 + rank)
