@@ -169,7 +169,8 @@ def model_workload(args, world, rank, dev):
     backbone = callers.ResNet(cfg["depth"], strides=(1, 2, 1, 1), dilations=(1, 1, 2, 4),
                               dcn=dict(dcn_type="depthdeform"), stage_with_dcn=(False, True, True, True),
                               norm_eval=False, deep_base=cfg["deep_base"])
-    model = callers.DANet(backbone, callers.DANetHead(2048, cfg["classes"]), callers.PointNet()).to(dev).train()
+    model = callers.DANet(backbone, callers.DANetHead(2048, cfg["classes"]), callers.PointNet(),
+                          dcn_offset_init=args.offset_init).to(dev).train()
     opt = callers.build_optimizer(model)
     g = torch.Generator().manual_seed(1234 + rank)
     label = torch.randint(0, cfg["classes"], (n, cfg["h"], cfg["w"]), generator=g)
@@ -206,7 +207,8 @@ def model_workload(args, world, rank, dev):
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": cfg["name"] + ", %d images/GPU, fwd+bwd+SGD step, random init" % n,
                        "images_per_gpu": n, "parallelism": "dp%d" % world,
-                       "params_M": round(sum(p.numel() for p in model.parameters()) / 1e6, 2)},
+                       "params_M": round(sum(p.numel() for p in model.parameters()) / 1e6, 2),
+                       "dcn_offset_init": args.offset_init},
             "final_loss": round(float(loss), 4),
             "peak_mem_GB": round(torch.cuda.max_memory_allocated() / 2 ** 30, 2),
         }), flush=True)
@@ -222,6 +224,9 @@ def main():
     ap.add_argument("--size", type=int, default=97)
     ap.add_argument("--dilation", type=int, default=4)
     ap.add_argument("--workload", choices=("layer", "r50", "r101"), default="layer")
+    ap.add_argument("--offset-init", choices=("zero", "kaiming"), default="zero",
+                    help="model workloads: DDCN offset convolutions start at zero (the reference's intent) or Kaiming "
+                         "(what its init_weights really does: ~6 px offsets)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     args = ap.parse_args()

@@ -82,13 +82,13 @@ class DANet(nn.Module):
     """segmentors/DANet.py:7-43 + single_stage.py forward_train / simple_test, for an RGB image and an HHA (or any
     3-channel depth encoding) image."""
 
-    def __init__(self, backbone, head, backbone_depth=None):
+    def __init__(self, backbone, head, backbone_depth=None, dcn_offset_init="zero"):
         super().__init__()
         self.backbone, self.head, self.backbone_depth = backbone, head, backbone_depth
-        self.init_weights()
+        self.init_weights(dcn_offset_init)
 
-    def init_weights(self):
-        self.backbone.init_weights()
+    def init_weights(self, dcn_offset_init="zero"):
+        self.backbone.init_weights(dcn_offset_init=dcn_offset_init)
         if self.backbone_depth is not None:
             self.backbone_depth.init_weights()
         self.head.init_weights()

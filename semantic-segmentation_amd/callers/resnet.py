@@ -122,9 +122,13 @@ class ResNet(nn.Module):
             self.res_layers.append(name)
         self.feat_dim = Bottleneck.expansion * 64 * 2 ** (len(self.stage_blocks) - 1)
 
-    def init_weights(self, pretrained=None):
-        """R:508-529 with pretrained=None: Kaiming-normal (fan_out, relu) for every nn.Conv2d -- which includes the
-        DDCN layers' conv_offset, as in the reference --, BN to 1/0, the last BN of each block to 0."""
+    def init_weights(self, pretrained=None, dcn_offset_init="zero"):
+        """R:508-529 with pretrained=None: Kaiming-normal (fan_out, relu) for every nn.Conv2d, BN to 1/0, the last
+        BN of each block to 0.  dcn_offset_init: the reference then means to zero the offset convolutions
+        (R:518-522) but tests for an attribute of an older API (`conv2_offset`), so its Kaiming pass -- which also
+        visits the DDCN layers' conv_offset, an nn.Conv2d -- stands and a randomly initialised model samples
+        ~6 px off the grid.  "zero" (default) applies the evident intent, i.e. the layers' own init_offset();
+        "kaiming" reproduces the reference literally."""
         if pretrained is not None:
             raise TypeError("checkpoints are loaded by the caller (no network, no pickles here)")
         for m in self.modules():
@@ -135,6 +139,12 @@ class ResNet(nn.Module):
             elif isinstance(m, (_BatchNorm, nn.GroupNorm)):
                 nn.init.constant_(m.weight, 1)
                 nn.init.constant_(m.bias, 0)
+        if dcn_offset_init == "zero":
+            for m in self.modules():
+                if isinstance(m, Bottleneck) and hasattr(m.conv2, "init_offset"):
+                    m.conv2.init_offset()
+        elif dcn_offset_init != "kaiming":
+            raise ValueError("dcn_offset_init must be 'zero' or 'kaiming'")
         if self.zero_init_residual:
             for m in self.modules():
                 if isinstance(m, Bottleneck):

@@ -42,10 +42,14 @@ def test_ddcn_r50_layer_plan():
               "backbone.layer2.0.downsample.1.weight", "backbone_depth.layer1.conv.weight",
               "backbone_depth.layer5.bn.bias", "head.sa.gamma", "head.conv5a.0.weight", "head.conv8.1.bias"):
         assert k in keys, k
-    # zero_init_residual and the DDCN mask branch start at zero; conv_offset is re-initialised like every nn.Conv2d
+    # zero_init_residual, and both DDCN branches start at zero (the reference's intent, resnet.py:518-522) ...
     assert float(m.backbone.layer3[0].bn3.weight.detach().abs().sum()) == 0
     assert float(m.backbone.layer3[0].conv2.conv_mask.weight.detach().abs().sum()) == 0
+    assert float(m.backbone.layer3[0].conv2.conv_offset.weight.detach().abs().sum()) == 0
+    # ... unless asked for what the reference's init_weights literally does: Kaiming on every nn.Conv2d
+    m.init_weights("kaiming")
     assert float(m.backbone.layer3[0].conv2.conv_offset.weight.detach().abs().sum()) > 0
+    assert float(m.backbone.layer3[0].conv2.conv_mask.weight.detach().abs().sum()) == 0
 
 
 def test_ddcn_r101_deep_base_counts():

@@ -23,7 +23,8 @@ def _model(depth=50, classes=40, deep_base=False):
     torch.manual_seed(0)
     bb = callers.ResNet(depth, strides=(1, 2, 1, 1), dilations=(1, 1, 2, 4), dcn=dict(dcn_type="depthdeform"),
                         stage_with_dcn=(False, True, True, True), norm_eval=False, deep_base=deep_base)
-    m = callers.DANet(bb, callers.DANetHead(2048, classes), callers.PointNet())
+    # Kaiming offset convolutions: non-trivial sampling positions in every DDCN layer
+    m = callers.DANet(bb, callers.DANetHead(2048, classes), callers.PointNet(), dcn_offset_init="kaiming")
     with torch.no_grad():   # zero_init_residual starts every residual branch (and its gradients) at exactly zero
         for mod in m.modules():
             if isinstance(mod, callers.Bottleneck):
