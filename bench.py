@@ -172,6 +172,8 @@ def model_workload(args, world, rank, dev):
     model = callers.DANet(backbone, callers.DANetHead(2048, cfg["classes"]), callers.PointNet(),
                           dcn_offset_init=args.offset_init).to(dev).train()
     opt = callers.build_optimizer(model)
+    # N > 1: gradient buckets are all-reduced (RCCL) from inside backward; --sync-allreduce reduces after it
+    reducer = callers.OverlappedGradReducer(model) if (world > 1 and not args.sync_allreduce) else None
     g = torch.Generator().manual_seed(1234 + rank)
     label = torch.randint(0, cfg["classes"], (n, cfg["h"], cfg["w"]), generator=g)
     label[torch.rand(n, cfg["h"], cfg["w"], generator=g) < 0.05] = 255      # 5 % ignored (configs: ignore_index=255)
@@ -180,7 +182,7 @@ def model_workload(args, world, rank, dev):
     total = args.warmup + args.steps
     it = 0
     for _ in range(args.warmup):
-        callers.train_step(model, opt, batch, it, total)
+        callers.train_step(model, opt, batch, it, total, reducer=reducer)
         it += 1
     torch.cuda.synchronize()
     if world > 1:
@@ -188,7 +190,7 @@ def model_workload(args, world, rank, dev):
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        loss = callers.train_step(model, opt, batch, it, total)
+        loss = callers.train_step(model, opt, batch, it, total, reducer=reducer)
         it += 1
     torch.cuda.synchronize()
     if world > 1:
@@ -208,7 +210,9 @@ def model_workload(args, world, rank, dev):
             "config": {"workload": cfg["name"] + ", %d images/GPU, fwd+bwd+SGD step, random init" % n,
                        "images_per_gpu": n, "parallelism": "dp%d" % world,
                        "params_M": round(sum(p.numel() for p in model.parameters()) / 1e6, 2),
-                       "dcn_offset_init": args.offset_init},
+                       "dcn_offset_init": args.offset_init,
+                       "allreduce": "none" if world == 1 else ("after backward" if reducer is None else
+                                                               "32 MiB buckets, overlapped with backward")},
             "final_loss": round(float(loss), 4),
             "peak_mem_GB": round(torch.cuda.max_memory_allocated() / 2 ** 30, 2),
         }), flush=True)
@@ -227,6 +231,8 @@ def main():
     ap.add_argument("--offset-init", choices=("zero", "kaiming"), default="zero",
                     help="model workloads: DDCN offset convolutions start at zero (the reference's intent) or Kaiming "
                          "(what its init_weights really does: ~6 px offsets)")
+    ap.add_argument("--sync-allreduce", action="store_true",
+                    help="model workloads, N > 1: all-reduce after backward (the reference's order) instead of under it")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     args = ap.parse_args()

@@ -10,7 +10,7 @@ the reference's code implies instead.
 from .resnet import Bottleneck, ResNet, make_res_layer
 from .pointnet import PointNet
 from .danet import CAM_Module, DANet, DANetHead, PAM_Module
-from .train import build_optimizer, poly_lr, train_step
+from .train import OverlappedGradReducer, build_optimizer, poly_lr, train_step
 
 __all__ = ["Bottleneck", "ResNet", "make_res_layer", "PointNet", "CAM_Module", "DANet", "DANetHead", "PAM_Module",
-           "build_optimizer", "poly_lr", "train_step"]
+           "OverlappedGradReducer", "build_optimizer", "poly_lr", "train_step"]
