@@ -218,6 +218,54 @@ def model_workload(args, world, rank, dev):
         }), flush=True)
 
 
+def inference_workload(args, world, rank, dev):
+    """BASELINE configs[4]: modulated DDCN (offset + mask, deformable_groups 4) in every ResNet stage, bf16
+    activations / weights with fp32 accumulation, 1024x2048 inference, one image per step and GPU (replicas: the
+    path does not shard below an image).  DDCN layers run the native bf16 kernels (ddcn_bf16.hip)."""
+    callers = importlib.import_module("semantic-segmentation_amd.callers")
+    torch.manual_seed(0)
+    backbone = callers.ResNet(101, strides=(1, 2, 1, 1), dilations=(1, 1, 2, 4),
+                              dcn=dict(dcn_type="modulated", deformable_groups=4),
+                              stage_with_dcn=(True, True, True, True), norm_eval=True)
+    model = callers.DANet(backbone, callers.DANetHead(2048, 19), None, dcn_offset_init=args.offset_init)
+    model = model.to(dev).bfloat16().eval()
+    n = 1 if args.batch == 2 else args.batch
+    g = torch.Generator().manual_seed(1234 + rank)
+    img = torch.randn(n, 3, 1024, 2048, generator=g).to(dev).bfloat16()
+    with torch.no_grad():
+        for _ in range(args.warmup):
+            out = model(img)
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            out = model(img)
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+    if rank == 0:
+        n_dcn = sum(1 for m in model.modules() if type(m).__name__ == "ModulatedDeformConvPack")
+        print(json.dumps({
+            "metric": "inference images/sec", "value": round(n * world * args.steps / dt, 3), "unit": "images/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": "BASELINE configs[4]: ResNet101 with modulated DDCN (dg=4) in all %d bottlenecks + "
+                                   "DANet head, 1024x2048 inference, %d image/GPU, random init" % (n_dcn, n),
+                       "images_per_gpu": n, "parallelism": "replicas%d" % world, "dcn_offset_init": args.offset_init},
+            "output_shape": list(out.shape), "finite": bool(torch.isfinite(out.float()).all()),
+            "peak_mem_GB": round(torch.cuda.max_memory_allocated() / 2 ** 30, 2),
+        }), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -227,7 +275,7 @@ def main():
     ap.add_argument("--channels", type=int, default=512)
     ap.add_argument("--size", type=int, default=97)
     ap.add_argument("--dilation", type=int, default=4)
-    ap.add_argument("--workload", choices=("layer", "r50", "r101"), default="layer")
+    ap.add_argument("--workload", choices=("layer", "r50", "r101", "cfg5"), default="layer")
     ap.add_argument("--offset-init", choices=("zero", "kaiming"), default="zero",
                     help="model workloads: DDCN offset convolutions start at zero (the reference's intent) or Kaiming "
                          "(what its init_weights really does: ~6 px offsets)")
@@ -249,6 +297,11 @@ def main():
     pkg = importlib.import_module("semantic-segmentation_amd")
     dist_utils = importlib.import_module("semantic-segmentation_amd.dist_utils")
 
+    if args.workload == "cfg5":
+        inference_workload(args, world, rank, dev)
+        if world > 1:
+            dist.destroy_process_group()
+        return
     if args.workload != "layer":
         model_workload(args, world, rank, dev)
         if world > 1:

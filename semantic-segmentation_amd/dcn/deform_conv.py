@@ -419,9 +419,35 @@ class _DeformConvSigmoidFunction(Function):
         return (grad_input, grad_offset, grad_weight, grad_bias, None, None, None, None, None)
 
 
-deform_conv = DeformConvFunction.apply
-modulated_deform_conv = ModulatedDeformConvFunction.apply
-depthaware_conv = DepthawareConvFunction.apply
+def _inference_view(tensors):
+    """Inside Function.forward a Parameter looks the same with and without torch.no_grad() (requires_grad stays
+    True), so the reference saves its tensors for a backward that can never come.  The functional aliases below hand
+    the Functions detached tensors when grad mode is off: nothing is saved, no columns are kept, and bfloat16
+    calls take the native bf16 kernels."""
+    if torch.is_grad_enabled():
+        return tensors
+    return tuple(t.detach() if isinstance(t, torch.Tensor) else t for t in tensors)
+
+
+def deform_conv(input, offset, weight, bias=None, stride=1, padding=0, dilation=1, groups=1, deformable_groups=1):
+    """`DeformConvFunction.apply` (PY:226) with the reference's positional argument order."""
+    input, offset, weight, bias = _inference_view((input, offset, weight, bias))
+    return DeformConvFunction.apply(input, offset, weight, bias, stride, padding, dilation, groups,
+                                    deformable_groups)
+
+
+def modulated_deform_conv(input, offset, mask, weight, bias=None, stride=1, padding=0, dilation=1, groups=1,
+                          deformable_groups=1):
+    """`ModulatedDeformConvFunction.apply` (PY:227) with the reference's positional argument order."""
+    input, offset, mask, weight, bias = _inference_view((input, offset, mask, weight, bias))
+    return ModulatedDeformConvFunction.apply(input, offset, mask, weight, bias, stride, padding, dilation, groups,
+                                             deformable_groups)
+
+
+def depthaware_conv(input, depth, weight, bias=None, stride=1, padding=0, dilation=1, groups=1):
+    """`DepthawareConvFunction.apply` (PY:228) with the reference's positional argument order."""
+    input, depth, weight, bias = _inference_view((input, depth, weight, bias))
+    return DepthawareConvFunction.apply(input, depth, weight, bias, stride, padding, dilation, groups)
 
 
 class _DcnConvBase(nn.Module):
@@ -573,7 +599,8 @@ class DepthDeformConvPack(ModulatedDeformConv):
         k2x2 = 2 * self.kernel_size[0] * self.kernel_size[1]
         mask_offset = offset if self.deformable_groups == 1 else offset[:, :k2x2].contiguous()
         cm = self.conv_mask
-        mask = _DeformConvSigmoidFunction.apply(depth, mask_offset, cm.weight, cm.bias, cm.stride, cm.padding,
+        depth_v, mask_offset, cm_weight, cm_bias = _inference_view((depth, mask_offset, cm.weight, cm.bias))
+        mask = _DeformConvSigmoidFunction.apply(depth_v, mask_offset, cm_weight, cm_bias, cm.stride, cm.padding,
                                                 cm.dilation, cm.groups, cm.deformable_groups)
         self.offset, self.mask = offset, mask
         return modulated_deform_conv(x, offset, mask, self.weight, self.bias,
