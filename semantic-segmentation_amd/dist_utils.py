@@ -1,51 +1,59 @@
 """Data-parallel gradient exchange for the DDCN layers: the only collective on the path.
 
-Mirrors `detseg/core/utils/dist_utils.py:9-41` of the reference (`allreduce_grads` /
-`_allreduce_coalesced`): gradients are flattened into buckets per tensor type, all-reduced (SUM) and divided
-by the world size, then copied back.  `torch.distributed` backend "nccl" is RCCL over xGMI on MI355X; the
-same code runs on gloo for the CPU tests.  Unlike the reference's default (one bucket holding every
-gradient, issued after backward), the default bucket here is 32 MiB so that several RCCL calls pipeline
-over the 7 xGMI links.
+Same contract as the reference's `allreduce_grads` / `_allreduce_coalesced`
+(`detseg/core/utils/dist_utils.py:9-41`): every existing gradient is summed over the ranks and divided by the world
+size, in place.  `torch.distributed` backend "nccl" is RCCL over xGMI on MI355X; the same code runs on gloo for the
+CPU tests.  The reference's default packs every gradient of one tensor type into a single flat buffer, reduced
+after backward; the default here is 32 MiB buckets, so that several RCCL calls pipeline over the 7 xGMI links
+(`callers/train.py:OverlappedGradReducer` additionally issues them from inside backward).
 """
-from collections import OrderedDict
-
 import torch
 import torch.distributed as dist
-from torch._utils import _flatten_dense_tensors, _take_tensors, _unflatten_dense_tensors
+
+
+def _split_into_buckets(tensors, bucket_size_mb):
+    """Lists of same-dtype tensors: at most `bucket_size_mb` each, or one list per dtype when it is <= 0."""
+    by_kind = {}
+    for t in tensors:
+        by_kind.setdefault((t.dtype, t.device), []).append(t)
+    limit = bucket_size_mb * 1024 * 1024 if bucket_size_mb > 0 else None
+    for group in by_kind.values():
+        if limit is None:
+            yield group
+            continue
+        bucket, used = [], 0
+        for t in group:
+            nbytes = t.numel() * t.element_size()
+            if bucket and used + nbytes > limit:
+                yield bucket
+                bucket, used = [], 0
+            bucket.append(t)
+            used += nbytes
+        if bucket:
+            yield bucket
 
 
 def _allreduce_coalesced(tensors, world_size, bucket_size_mb=-1):
-    # dist_utils.py:9-28
-    if bucket_size_mb > 0:
-        bucket_size_bytes = bucket_size_mb * 1024 * 1024
-        buckets = _take_tensors(tensors, bucket_size_bytes)
-    else:
-        buckets = OrderedDict()
-        for tensor in tensors:
-            tp = tensor.type()
-            if tp not in buckets:
-                buckets[tp] = []
-            buckets[tp].append(tensor)
-        buckets = buckets.values()
-
-    for bucket in buckets:
-        flat_tensors = _flatten_dense_tensors(bucket)
-        dist.all_reduce(flat_tensors)
-        flat_tensors.div_(world_size)
-        for tensor, synced in zip(bucket, _unflatten_dense_tensors(flat_tensors, bucket)):
-            tensor.copy_(synced)
+    for bucket in _split_into_buckets(tensors, bucket_size_mb):
+        flat = torch.cat([t.reshape(-1) for t in bucket])
+        dist.all_reduce(flat)          # SUM ...
+        flat.div_(world_size)          # ... then the mean, as the reference does
+        start = 0
+        for t in bucket:
+            t.copy_(flat[start:start + t.numel()].view_as(t))
+            start += t.numel()
 
 
 def allreduce_grads(model_or_params, coalesce=True, bucket_size_mb=32):
-    """SUM-then-divide all-reduce of every existing gradient (dist_utils.py:31-41)."""
+    """All-reduce (mean) the .grad of every parameter that has one; `coalesce=False` reduces tensor by tensor."""
     params = model_or_params.parameters() if hasattr(model_or_params, "parameters") else model_or_params
     grads = [p.grad.data for p in params if p.requires_grad and p.grad is not None]
     world_size = dist.get_world_size()
     if coalesce:
         _allreduce_coalesced(grads, world_size, bucket_size_mb)
-    else:
-        for tensor in grads:
-            dist.all_reduce(tensor.div_(world_size))
+        return
+    for g in grads:
+        dist.all_reduce(g.div_(world_size))
 
 
 def shard_batch(n_images, rank, world_size):
