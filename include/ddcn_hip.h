@@ -151,6 +151,44 @@ int ddcn_depthaware_conv_backward_f32(const float *x, const float *depth, const 
                                       const float *grad_out, float *gx, float *gw, float *gb, void *workspace,
                                       size_t workspace_bytes, const ddcn_geom *g, void *stream);
 
+/* ---------------------------------------------------------------- fp64
+ * The reference instantiates every kernel for double too (AT_DISPATCH_FLOATING_TYPES_AND_HALF, K:258) and its GPU
+ * self-test is an fp64 gradcheck (detseg/ops/dcn/test.py:208-267).  Same entry points as above with double tensors and
+ * a workspace of ddcn_workspace_bytes_f64() bytes; same rules (backward accumulates, columns may be NULL).  These
+ * kernels are for validation in double precision and are not tuned; the gw reduction is deterministic. */
+size_t ddcn_workspace_bytes_f64(const ddcn_geom *g);
+int ddcn_deform_conv_forward_f64(const double *x, const double *weight, const double *bias, const double *offset,
+                                 double *out, void *workspace, size_t workspace_bytes, const ddcn_geom *g,
+                                 void *stream);
+int ddcn_deform_conv_direct_forward_f64(const double *x, const double *weight, const double *bias,
+                                        const double *offset, double *out, int sigmoid, void *workspace,
+                                        size_t workspace_bytes, const ddcn_geom *g, void *stream);
+int ddcn_deform_conv_backward_f64(const double *x, const double *weight, const double *offset, const double *grad_out,
+                                  double *gx, double *goff, double *gw, double *gb, void *workspace,
+                                  size_t workspace_bytes, const ddcn_geom *g, void *stream);
+int ddcn_deform_conv_backward_saved_f64(const double *x, const double *weight, const double *offset,
+                                        const double *grad_out, const double *columns, double *gx, double *goff,
+                                        double *gw, double *gb, void *workspace, size_t workspace_bytes,
+                                        const ddcn_geom *g, void *stream);
+int ddcn_modulated_deform_conv_forward_f64(const double *x, const double *weight, const double *bias,
+                                           const double *offset, const double *mask, double *out, void *workspace,
+                                           size_t workspace_bytes, const ddcn_geom *g, void *stream);
+int ddcn_modulated_deform_conv_backward_f64(const double *x, const double *weight, const double *offset,
+                                            const double *mask, const double *grad_out, double *gx, double *goff,
+                                            double *gmask, double *gw, double *gb, void *workspace,
+                                            size_t workspace_bytes, const ddcn_geom *g, void *stream);
+int ddcn_modulated_deform_conv_backward_saved_f64(const double *x, const double *weight, const double *offset,
+                                                  const double *mask, const double *grad_out, const double *columns,
+                                                  double *gx, double *goff, double *gmask, double *gw, double *gb,
+                                                  void *workspace, size_t workspace_bytes, const ddcn_geom *g,
+                                                  void *stream);
+int ddcn_depthaware_conv_forward_f64(const double *x, const double *depth, const double *weight, const double *bias,
+                                     double *out, void *workspace, size_t workspace_bytes, const ddcn_geom *g,
+                                     void *stream);
+int ddcn_depthaware_conv_backward_f64(const double *x, const double *depth, const double *weight,
+                                      const double *grad_out, double *gx, double *gw, double *gb, void *workspace,
+                                      size_t workspace_bytes, const ddcn_geom *g, void *stream);
+
 /* ---------------------------------------------------------------- native bf16 forward (inference)
  * No counterpart in the reference (it dispatches fp64/fp32/fp16 only, K:258): BASELINE config 5, "bf16 activations with
  * fp32 accumulation".  Every tensor pointer is bfloat16 (torch.bfloat16 data_ptr()): x, weight, bias, offset, mask,

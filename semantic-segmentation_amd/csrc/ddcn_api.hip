@@ -328,6 +328,116 @@ int ddcn_depthaware_conv_backward_f32(const float *x, const float *depth, const 
     return DDCN_OK;
 }
 
+// ---------------------------------------------------------------- fp64
+size_t ddcn_workspace_bytes_f64(const ddcn_geom *g)
+{
+    if (check_geom(g) != DDCN_OK) return 0;
+    return f64_workspace_bytes(*g);
+}
+
+static int check_ws_f64(const ddcn_geom *g, void *ws, size_t bytes)
+{
+    if (!ws || bytes < f64_workspace_bytes(*g))
+        return fail(DDCN_ERR_WORKSPACE, "fp64 workspace of %zu bytes, need %zu", bytes, f64_workspace_bytes(*g));
+    return DDCN_OK;
+}
+
+int ddcn_deform_conv_forward_f64(const double *x, const double *weight, const double *bias, const double *offset,
+                                 double *out, void *workspace, size_t workspace_bytes, const ddcn_geom *g,
+                                 void *stream)
+{
+    REQUIRE(x); REQUIRE(weight); REQUIRE(offset); REQUIRE(out);
+    TRY(check_geom(g));
+    TRY(check_ws_f64(g, workspace, workspace_bytes));
+    return f64_forward(x, weight, bias, offset, nullptr, nullptr, out, 0, (double *)workspace, *g, (hipStream_t)stream);
+}
+
+int ddcn_deform_conv_direct_forward_f64(const double *x, const double *weight, const double *bias,
+                                        const double *offset, double *out, int sigmoid, void *workspace,
+                                        size_t workspace_bytes, const ddcn_geom *g, void *stream)
+{
+    REQUIRE(x); REQUIRE(weight); REQUIRE(offset); REQUIRE(out);
+    TRY(check_geom(g));
+    TRY(check_ws_f64(g, workspace, workspace_bytes));
+    return f64_forward(x, weight, bias, offset, nullptr, nullptr, out, sigmoid, (double *)workspace, *g,
+                       (hipStream_t)stream);
+}
+
+int ddcn_modulated_deform_conv_forward_f64(const double *x, const double *weight, const double *bias,
+                                           const double *offset, const double *mask, double *out, void *workspace,
+                                           size_t workspace_bytes, const ddcn_geom *g, void *stream)
+{
+    REQUIRE(x); REQUIRE(weight); REQUIRE(offset); REQUIRE(mask); REQUIRE(out);
+    TRY(check_geom(g));
+    TRY(check_ws_f64(g, workspace, workspace_bytes));
+    return f64_forward(x, weight, bias, offset, mask, nullptr, out, 0, (double *)workspace, *g, (hipStream_t)stream);
+}
+
+int ddcn_depthaware_conv_forward_f64(const double *x, const double *depth, const double *weight, const double *bias,
+                                     double *out, void *workspace, size_t workspace_bytes, const ddcn_geom *g,
+                                     void *stream)
+{
+    REQUIRE(x); REQUIRE(depth); REQUIRE(weight); REQUIRE(out);
+    TRY(check_geom(g));
+    TRY(check_ws_f64(g, workspace, workspace_bytes));
+    return f64_forward(x, weight, bias, nullptr, nullptr, depth, out, 0, (double *)workspace, *g, (hipStream_t)stream);
+}
+
+int ddcn_deform_conv_backward_saved_f64(const double *x, const double *weight, const double *offset,
+                                        const double *grad_out, const double *columns, double *gx, double *goff,
+                                        double *gw, double *gb, void *workspace, size_t workspace_bytes,
+                                        const ddcn_geom *g, void *stream)
+{
+    REQUIRE(x); REQUIRE(weight); REQUIRE(offset); REQUIRE(grad_out); REQUIRE(gx); REQUIRE(goff); REQUIRE(gw);
+    TRY(check_geom(g));
+    TRY(check_ws_f64(g, workspace, workspace_bytes));
+    return f64_backward(x, weight, offset, nullptr, nullptr, grad_out, columns, gx, goff, nullptr, gw, gb,
+                        (double *)workspace, *g, (hipStream_t)stream);
+}
+
+int ddcn_deform_conv_backward_f64(const double *x, const double *weight, const double *offset, const double *grad_out,
+                                  double *gx, double *goff, double *gw, double *gb, void *workspace,
+                                  size_t workspace_bytes, const ddcn_geom *g, void *stream)
+{
+    return ddcn_deform_conv_backward_saved_f64(x, weight, offset, grad_out, nullptr, gx, goff, gw, gb, workspace,
+                                               workspace_bytes, g, stream);
+}
+
+int ddcn_modulated_deform_conv_backward_saved_f64(const double *x, const double *weight, const double *offset,
+                                                  const double *mask, const double *grad_out, const double *columns,
+                                                  double *gx, double *goff, double *gmask, double *gw, double *gb,
+                                                  void *workspace, size_t workspace_bytes, const ddcn_geom *g,
+                                                  void *stream)
+{
+    REQUIRE(x); REQUIRE(weight); REQUIRE(offset); REQUIRE(mask); REQUIRE(grad_out);
+    REQUIRE(gx); REQUIRE(goff); REQUIRE(gmask); REQUIRE(gw);
+    TRY(check_geom(g));
+    TRY(check_ws_f64(g, workspace, workspace_bytes));
+    return f64_backward(x, weight, offset, mask, nullptr, grad_out, columns, gx, goff, gmask, gw, gb,
+                        (double *)workspace, *g, (hipStream_t)stream);
+}
+
+int ddcn_modulated_deform_conv_backward_f64(const double *x, const double *weight, const double *offset,
+                                            const double *mask, const double *grad_out, double *gx, double *goff,
+                                            double *gmask, double *gw, double *gb, void *workspace,
+                                            size_t workspace_bytes, const ddcn_geom *g, void *stream)
+{
+    return ddcn_modulated_deform_conv_backward_saved_f64(x, weight, offset, mask, grad_out, nullptr, gx, goff, gmask,
+                                                         gw, gb, workspace, workspace_bytes, g, stream);
+}
+
+int ddcn_depthaware_conv_backward_f64(const double *x, const double *depth, const double *weight,
+                                      const double *grad_out, double *gx, double *gw, double *gb, void *workspace,
+                                      size_t workspace_bytes, const ddcn_geom *g, void *stream)
+{
+    REQUIRE(x); REQUIRE(depth); REQUIRE(weight); REQUIRE(grad_out); REQUIRE(gx); REQUIRE(gw);
+    TRY(check_geom(g));
+    TRY(check_ws_f64(g, workspace, workspace_bytes));
+    return f64_backward(x, weight, nullptr, nullptr, depth, grad_out, nullptr, gx, nullptr, nullptr, gw, gb,
+                        (double *)workspace, *g, (hipStream_t)stream);
+}
+
+// ---------------------------------------------------------------- bf16
 size_t ddcn_workspace_bytes_bf16(const ddcn_geom *g)
 {
     if (check_geom(g) != DDCN_OK) return 0;

@@ -58,6 +58,13 @@ int launch_gemm_out(const float *weight, const float *col, const float *bias, fl
 int launch_gemm_gcol(const float *weight, const float *gout, float *gcol, const ddcn_geom &g, hipStream_t stream);
 int launch_gemm_gweight(const float *gout, const float *col, float *gw, const ddcn_geom &g, hipStream_t stream);
 
+size_t f64_workspace_bytes(const ddcn_geom &g);
+int f64_forward(const double *x, const double *weight, const double *bias, const double *offset, const double *mask,
+                const double *depth, double *out, int sigmoid, double *col, const ddcn_geom &g, hipStream_t s);
+int f64_backward(const double *x, const double *weight, const double *offset, const double *mask, const double *depth,
+                 const double *gout, const double *saved_cols, double *gx, double *goff, double *gmask, double *gw,
+                 double *gb, double *col, const ddcn_geom &g, hipStream_t s);
+
 size_t bf16_workspace_bytes(const ddcn_geom &g);
 int bf16_supported(const ddcn_geom &g);
 int launch_forward_bf16(const void *x, const void *weight, const void *bias, const void *offset, const void *mask,

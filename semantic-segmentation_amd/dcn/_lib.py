@@ -58,6 +58,16 @@ PROTOTYPES = {
     "ddcn_modulated_deform_conv_backward_saved_f32": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _SZ, _G, _P],
     "ddcn_depthaware_conv_forward_f32": [_P, _P, _P, _P, _P, _P, _SZ, _G, _P],
     "ddcn_depthaware_conv_backward_f32": [_P, _P, _P, _P, _P, _P, _P, _P, _SZ, _G, _P],
+    "ddcn_workspace_bytes_f64": [_G],
+    "ddcn_deform_conv_forward_f64": [_P, _P, _P, _P, _P, _P, _SZ, _G, _P],
+    "ddcn_deform_conv_direct_forward_f64": [_P, _P, _P, _P, _P, ctypes.c_int, _P, _SZ, _G, _P],
+    "ddcn_deform_conv_backward_f64": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _SZ, _G, _P],
+    "ddcn_deform_conv_backward_saved_f64": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _SZ, _G, _P],
+    "ddcn_modulated_deform_conv_forward_f64": [_P, _P, _P, _P, _P, _P, _P, _SZ, _G, _P],
+    "ddcn_modulated_deform_conv_backward_f64": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _SZ, _G, _P],
+    "ddcn_modulated_deform_conv_backward_saved_f64": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _SZ, _G, _P],
+    "ddcn_depthaware_conv_forward_f64": [_P, _P, _P, _P, _P, _P, _SZ, _G, _P],
+    "ddcn_depthaware_conv_backward_f64": [_P, _P, _P, _P, _P, _P, _P, _P, _SZ, _G, _P],
     "ddcn_workspace_bytes_bf16": [_G],
     "ddcn_bf16_supported": [_G],
     "ddcn_modulated_deform_conv_forward_bf16": [_P, _P, _P, _P, _P, _P, _P, _SZ, _G, _P],
@@ -70,6 +80,7 @@ _RESTYPES = {
     "ddcn_col_ld": _SZ,
     "ddcn_workspace_bytes": _SZ,
     "ddcn_workspace_bytes_bf16": _SZ,
+    "ddcn_workspace_bytes_f64": _SZ,
 }
 
 _lib = None

@@ -43,17 +43,17 @@ def _geom(input, weight, stride, padding, dilation, groups, deformable_groups):
     return g
 
 
-_DTYPES = (torch.float32, torch.float16, torch.bfloat16)
+_DTYPES = (torch.float32, torch.float64, torch.float16, torch.bfloat16)
 
 
 def _check_dtype_cuda(name, t, dtype):
-    """The reference dispatches on FLOATING_TYPES_AND_HALF (deform_conv_cuda_kernel.cu:258).  Here the kernels are
-    fp32: half / bfloat16 tensors are accepted and computed in fp32 (converted on the way in and out, so the result
-    is at least as accurate as a native half kernel); float64 is refused."""
+    """The reference dispatches on FLOATING_TYPES_AND_HALF (deform_conv_cuda_kernel.cu:258).  Here float32 and
+    float64 have their own kernels; half / bfloat16 tensors are computed by the fp32 kernels (converted on the way
+    in and out, so the result is at least as accurate as a native half kernel), bfloat16 inference by the bf16 ones."""
     if not t.is_cuda:
         raise NotImplementedError
     if dtype not in _DTYPES:
-        raise RuntimeError("ddcn: %s dtype not supported (float32, float16, bfloat16)" % (dtype,))
+        raise RuntimeError("ddcn: %s dtype not supported (float32, float64, float16, bfloat16)" % (dtype,))
     if t.dtype != dtype:
         raise RuntimeError("ddcn: %s is %s but input is %s; all tensors of one call must share a dtype"
                            % (name, t.dtype, dtype))
@@ -61,6 +61,20 @@ def _check_dtype_cuda(name, t, dtype):
 
 def _f32(t):
     return t if t.dtype == torch.float32 else t.float()
+
+
+def _cdtype(dtype):
+    """Dtype the kernels compute a call in: float64 tensors by the fp64 kernels, everything else in fp32."""
+    return torch.float64 if dtype == torch.float64 else torch.float32
+
+
+def _cast(t, cd):
+    return t if t.dtype == cd else t.to(cd)
+
+
+def _entry(name, cd):
+    """The C ABI entry point `name` for compute dtype cd (ddcn_*_f32 / ddcn_*_f64)."""
+    return getattr(_lib.lib(), name + ("_f64" if cd == torch.float64 else "_f32"))
 
 
 def _contig(name, t):
@@ -95,7 +109,10 @@ def _bf16_forward(input, offset, mask, weight, bias, g):
     return output
 
 
-def _workspace(input, g):
+def _workspace(input, g, cd=torch.float32):
+    if cd == torch.float64:
+        nbytes = _lib.lib().ddcn_workspace_bytes_f64(g)
+        return torch.empty(nbytes // 8, dtype=torch.float64, device=input.device), nbytes
     nbytes = _lib.lib().ddcn_workspace_bytes(g)
     return torch.empty(nbytes // 4, dtype=torch.float32, device=input.device), nbytes
 
@@ -150,6 +167,7 @@ class DeformConvFunction(Function):
         for name, t in (("input", input), ("offset", offset), ("weight", weight), ("bias", bias)):
             _check_dtype_cuda(name, t, input.dtype)
         ctx.dtype = input.dtype
+        cd = _cdtype(ctx.dtype)
         _contig("input", input)
         _contig("weight", weight)
         g = _geom(input, weight, stride, padding, dilation, groups, deformable_groups)
@@ -163,38 +181,39 @@ class DeformConvFunction(Function):
             output = _bf16_forward(input, offset, None, weight, bias if ctx.with_bias else None, g)
             if output is not None:
                 return output
-        input, offset, weight, bias = (_f32(t) for t in (input, offset, weight, bias))
+        input, offset, weight, bias = (_cast(t, cd) for t in (input, offset, weight, bias))
         output = input.new_empty(
             DeformConvFunction._infer_shape(ctx, input, weight))
-        ws, ws_bytes = _workspace(input, g)
+        ws, ws_bytes = _workspace(input, g, cd)
         with torch.cuda.device(input.device):
-            _lib.check(_lib.lib().ddcn_deform_conv_forward_f32(
+            _lib.check(_entry("ddcn_deform_conv_forward", cd)(
                 _lib.ptr(input), _lib.ptr(weight), _lib.ptr(bias) if ctx.with_bias else None, _lib.ptr(offset),
                 _lib.ptr(output), _lib.ptr(ws), ws_bytes, g, _lib.current_stream(input.device)))
         ctx.columns = ws if (needs_grad and SAVE_COLUMNS) else None
-        return output if ctx.dtype == torch.float32 else output.to(ctx.dtype)
+        return output if ctx.dtype == cd else output.to(ctx.dtype)
 
     @staticmethod
     @once_differentiable
     def backward(ctx, grad_output):
         if not grad_output.is_cuda:
             raise NotImplementedError
-        input, offset, weight, bias = (_f32(t) for t in ctx.saved_tensors)
-        grad_output = _f32(grad_output.contiguous())
+        cd = _cdtype(ctx.dtype)
+        input, offset, weight, bias = (_cast(t, cd) for t in ctx.saved_tensors)
+        grad_output = _cast(grad_output.contiguous(), cd)
         grad_input, grad_offset, grad_weight, grad_bias = _zeros_like_all(input, offset, weight, bias)
         g = _geom(input, weight, ctx.stride, ctx.padding, ctx.dilation, ctx.groups, ctx.deformable_groups)
         _expect_shape("grad_output", grad_output, (g.N, g.Co, g.Ho, g.Wo))
-        ws, ws_bytes = _workspace(input, g)
+        ws, ws_bytes = _workspace(input, g, cd)
         with torch.cuda.device(input.device):
             cols, ctx.columns = getattr(ctx, "columns", None), None
-            _lib.check(_lib.lib().ddcn_deform_conv_backward_saved_f32(
+            _lib.check(_entry("ddcn_deform_conv_backward_saved", cd)(
                 _lib.ptr(input), _lib.ptr(weight), _lib.ptr(offset), _lib.ptr(grad_output),
                 _lib.ptr(cols) if cols is not None else None, _lib.ptr(grad_input),
                 _lib.ptr(grad_offset), _lib.ptr(grad_weight), _lib.ptr(grad_bias) if ctx.with_bias else None,
                 _lib.ptr(ws), ws_bytes, g, _lib.current_stream(input.device)))
         if not ctx.with_bias:
             grad_bias = None
-        if ctx.dtype != torch.float32:
+        if ctx.dtype != cd:
             grad_input, grad_offset, grad_weight, grad_bias = (
                 None if t is None else t.to(ctx.dtype) for t in (grad_input, grad_offset, grad_weight, grad_bias))
 
@@ -231,6 +250,7 @@ class ModulatedDeformConvFunction(Function):
         for name, t in (("input", input), ("offset", offset), ("mask", mask), ("weight", weight), ("bias", bias)):
             _check_dtype_cuda(name, t, input.dtype)
         ctx.dtype = input.dtype
+        cd = _cdtype(ctx.dtype)
         _contig("input", input)
         _contig("weight", weight)
         g = _geom(input, weight, stride, padding, dilation, groups, deformable_groups)
@@ -246,38 +266,39 @@ class ModulatedDeformConvFunction(Function):
             output = _bf16_forward(input, offset, mask, weight, bias if ctx.with_bias else None, g)
             if output is not None:
                 return output
-        input, offset, mask, weight, bias = (_f32(t) for t in (input, offset, mask, weight, bias))
+        input, offset, mask, weight, bias = (_cast(t, cd) for t in (input, offset, mask, weight, bias))
         output = input.new_empty(
             ModulatedDeformConvFunction._infer_shape(ctx, input, weight))
-        ws, ws_bytes = _workspace(input, g)
+        ws, ws_bytes = _workspace(input, g, cd)
         with torch.cuda.device(input.device):
-            _lib.check(_lib.lib().ddcn_modulated_deform_conv_forward_f32(
+            _lib.check(_entry("ddcn_modulated_deform_conv_forward", cd)(
                 _lib.ptr(input), _lib.ptr(weight), _lib.ptr(bias) if ctx.with_bias else None, _lib.ptr(offset),
                 _lib.ptr(mask), _lib.ptr(output), _lib.ptr(ws), ws_bytes, g, _lib.current_stream(input.device)))
         ctx.columns = ws if (needs_grad and SAVE_COLUMNS) else None
-        return output if ctx.dtype == torch.float32 else output.to(ctx.dtype)
+        return output if ctx.dtype == cd else output.to(ctx.dtype)
 
     @staticmethod
     @once_differentiable
     def backward(ctx, grad_output):
         if not grad_output.is_cuda:
             raise NotImplementedError
-        input, offset, mask, weight, bias = (_f32(t) for t in ctx.saved_tensors)
-        grad_output = _f32(grad_output.contiguous())
+        cd = _cdtype(ctx.dtype)
+        input, offset, mask, weight, bias = (_cast(t, cd) for t in ctx.saved_tensors)
+        grad_output = _cast(grad_output.contiguous(), cd)
         grad_input, grad_offset, grad_mask, grad_weight, grad_bias = _zeros_like_all(input, offset, mask, weight, bias)
         g = _geom(input, weight, ctx.stride, ctx.padding, ctx.dilation, ctx.groups, ctx.deformable_groups)
         _expect_shape("grad_output", grad_output, (g.N, g.Co, g.Ho, g.Wo))
-        ws, ws_bytes = _workspace(input, g)
+        ws, ws_bytes = _workspace(input, g, cd)
         with torch.cuda.device(input.device):
             cols, ctx.columns = getattr(ctx, "columns", None), None
-            _lib.check(_lib.lib().ddcn_modulated_deform_conv_backward_saved_f32(
+            _lib.check(_entry("ddcn_modulated_deform_conv_backward_saved", cd)(
                 _lib.ptr(input), _lib.ptr(weight), _lib.ptr(offset), _lib.ptr(mask), _lib.ptr(grad_output),
                 _lib.ptr(cols) if cols is not None else None, _lib.ptr(grad_input), _lib.ptr(grad_offset), _lib.ptr(grad_mask), _lib.ptr(grad_weight),
                 _lib.ptr(grad_bias) if ctx.with_bias else None, _lib.ptr(ws), ws_bytes, g,
                 _lib.current_stream(input.device)))
         if not ctx.with_bias:
             grad_bias = None
-        if ctx.dtype != torch.float32:
+        if ctx.dtype != cd:
             grad_input, grad_offset, grad_mask, grad_weight, grad_bias = (
                 None if t is None else t.to(ctx.dtype)
                 for t in (grad_input, grad_offset, grad_mask, grad_weight, grad_bias))
@@ -312,6 +333,7 @@ class DepthawareConvFunction(Function):
         for name, t in (("input", input), ("depth", depth), ("weight", weight), ("bias", bias)):
             _check_dtype_cuda(name, t, input.dtype)
         ctx.dtype = input.dtype
+        cd = _cdtype(ctx.dtype)
         _contig("input", input)
         _contig("weight", weight)
         g = _geom(input, weight, stride, padding, dilation, groups, 1)
@@ -319,37 +341,38 @@ class DepthawareConvFunction(Function):
         depth = depth.contiguous()
         if weight.requires_grad or input.requires_grad:
             ctx.save_for_backward(input, depth, weight, bias)
-        input, depth, weight, bias = (_f32(t) for t in (input, depth, weight, bias))
+        input, depth, weight, bias = (_cast(t, cd) for t in (input, depth, weight, bias))
         output = input.new_empty(
             DepthawareConvFunction._infer_shape(ctx, input, weight))
-        ws, ws_bytes = _workspace(input, g)
+        ws, ws_bytes = _workspace(input, g, cd)
         with torch.cuda.device(input.device):
-            _lib.check(_lib.lib().ddcn_depthaware_conv_forward_f32(
+            _lib.check(_entry("ddcn_depthaware_conv_forward", cd)(
                 _lib.ptr(input), _lib.ptr(depth), _lib.ptr(weight), _lib.ptr(bias) if ctx.with_bias else None,
                 _lib.ptr(output), _lib.ptr(ws), ws_bytes, g, _lib.current_stream(input.device)))
-        return output if ctx.dtype == torch.float32 else output.to(ctx.dtype)
+        return output if ctx.dtype == cd else output.to(ctx.dtype)
 
     @staticmethod
     @once_differentiable
     def backward(ctx, grad_output):
         if not grad_output.is_cuda:
             raise NotImplementedError
-        input, depth, weight, bias = (_f32(t) for t in ctx.saved_tensors)
-        grad_output = _f32(grad_output.contiguous())
+        cd = _cdtype(ctx.dtype)
+        input, depth, weight, bias = (_cast(t, cd) for t in ctx.saved_tensors)
+        grad_output = _cast(grad_output.contiguous(), cd)
         grad_input = torch.zeros_like(input)
         grad_weight = torch.zeros_like(weight)
         grad_bias = torch.zeros_like(bias)
         g = _geom(input, weight, ctx.stride, ctx.padding, ctx.dilation, ctx.groups, 1)
         _expect_shape("grad_output", grad_output, (g.N, g.Co, g.Ho, g.Wo))
-        ws, ws_bytes = _workspace(input, g)
+        ws, ws_bytes = _workspace(input, g, cd)
         with torch.cuda.device(input.device):
-            _lib.check(_lib.lib().ddcn_depthaware_conv_backward_f32(
+            _lib.check(_entry("ddcn_depthaware_conv_backward", cd)(
                 _lib.ptr(input), _lib.ptr(depth), _lib.ptr(weight), _lib.ptr(grad_output), _lib.ptr(grad_input),
                 _lib.ptr(grad_weight), _lib.ptr(grad_bias) if ctx.with_bias else None, _lib.ptr(ws), ws_bytes, g,
                 _lib.current_stream(input.device)))
         if not ctx.with_bias:
             grad_bias = None
-        if ctx.dtype != torch.float32:
+        if ctx.dtype != cd:
             grad_input, grad_weight, grad_bias = (
                 None if t is None else t.to(ctx.dtype) for t in (grad_input, grad_weight, grad_bias))
 
@@ -378,42 +401,44 @@ class _DeformConvSigmoidFunction(Function):
         for name, t in (("input", input), ("offset", offset), ("weight", weight), ("bias", bias)):
             _check_dtype_cuda(name, t, input.dtype)
         ctx.dtype = input.dtype
+        cd = _cdtype(ctx.dtype)
         _contig("input", input)
         _contig("weight", weight)
         g = _geom(input, weight, stride, padding, dilation, groups, deformable_groups)
         _expect_shape("offset", offset, (g.N, deformable_groups * 2 * g.kh * g.kw, g.Ho, g.Wo))
         offset = offset.contiguous()
         saved = (input, offset, weight, bias)
-        input, offset, weight, bias = (_f32(t) for t in saved)
+        input, offset, weight, bias = (_cast(t, cd) for t in saved)
         output = input.new_empty((g.N, g.Co, g.Ho, g.Wo))
-        ws, ws_bytes = _workspace(input, g)
+        ws, ws_bytes = _workspace(input, g, cd)
         with torch.cuda.device(input.device):
-            _lib.check(_lib.lib().ddcn_deform_conv_direct_forward_f32(
+            _lib.check(_entry("ddcn_deform_conv_direct_forward", cd)(
                 _lib.ptr(input), _lib.ptr(weight), _lib.ptr(bias) if ctx.with_bias else None, _lib.ptr(offset),
                 _lib.ptr(output), 1, _lib.ptr(ws), ws_bytes, g, _lib.current_stream(input.device)))
         ctx.save_for_backward(*saved, output)
-        return output if ctx.dtype == torch.float32 else output.to(ctx.dtype)
+        return output if ctx.dtype == cd else output.to(ctx.dtype)
 
     @staticmethod
     @once_differentiable
     def backward(ctx, grad_output):
         if not grad_output.is_cuda:
             raise NotImplementedError
+        cd = _cdtype(ctx.dtype)
         input, offset, weight, bias, out = ctx.saved_tensors
-        input, offset, weight, bias = (_f32(t) for t in (input, offset, weight, bias))
-        grad_pre = (_f32(grad_output) * out * (1.0 - out)).contiguous()      # d sigmoid
+        input, offset, weight, bias = (_cast(t, cd) for t in (input, offset, weight, bias))
+        grad_pre = (_cast(grad_output, cd) * out * (1.0 - out)).contiguous()      # d sigmoid
         grad_input, grad_offset, grad_weight, grad_bias = _zeros_like_all(input, offset, weight, bias)
         g = _geom(input, weight, ctx.stride, ctx.padding, ctx.dilation, ctx.groups, ctx.deformable_groups)
         _expect_shape("grad_output", grad_pre, (g.N, g.Co, g.Ho, g.Wo))
-        ws, ws_bytes = _workspace(input, g)
+        ws, ws_bytes = _workspace(input, g, cd)
         with torch.cuda.device(input.device):
-            _lib.check(_lib.lib().ddcn_deform_conv_backward_f32(
+            _lib.check(_entry("ddcn_deform_conv_backward", cd)(
                 _lib.ptr(input), _lib.ptr(weight), _lib.ptr(offset), _lib.ptr(grad_pre), _lib.ptr(grad_input),
                 _lib.ptr(grad_offset), _lib.ptr(grad_weight), _lib.ptr(grad_bias) if ctx.with_bias else None,
                 _lib.ptr(ws), ws_bytes, g, _lib.current_stream(input.device)))
         if not ctx.with_bias:
             grad_bias = None
-        if ctx.dtype != torch.float32:
+        if ctx.dtype != cd:
             grad_input, grad_offset, grad_weight, grad_bias = (
                 None if t is None else t.to(ctx.dtype) for t in (grad_input, grad_offset, grad_weight, grad_bias))
         return (grad_input, grad_offset, grad_weight, grad_bias, None, None, None, None, None)
