@@ -48,14 +48,27 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t s9_rsrc(const void *base, long
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(base), 0, n, 0x00020000);
 }
 
-template <bool MOD, int NCELL, int SC>
+// FX: the footprint is kept as 32-bit fixed point, two channels per 64-bit LDS word, and accumulated with ds_add_u64
+// (19 cycles per wave instruction for two channels against 2 x 23.5 for ds_add_f64).  Per chunk the workgroup takes the
+// largest |column value x mask| it is about to add, gmax < 2^e, and scales by 2^(19-e): every contribution is below
+// 2^19 in magnitude, and since the four corner weights of a sample sum to 1 a cell can collect at most
+// 256 pixels x 9 taps < 2^12 of them, so a field never leaves 31 bits.  Adding (hi << 32) + lo as ONE signed 64-bit
+// number is exact for both fields (the borrow of a negative low part is undone when the word is decoded as
+// lo = int32(word), hi = (word - lo) >> 32).  Resolution: 2^-19 of the chunk's largest column value per add.
+// A non-finite column value cannot be represented: the chunk then writes NaN to every cell it could have touched.
+template <bool MOD, int NCELL, int SC, bool FX>
 __global__ __launch_bounds__(ST, SC == 4 ? 2 : DDCN_S9_WPS) void col2im_coord_tile9_kernel(Tile9Args a)
 {
+    static_assert(!FX || SC == 4, "fixed-point footprint packs channel pairs of a 4-channel chunk");
     typedef float xvec __attribute__((ext_vector_type(SC)));
+    typedef unsigned long long u64;
     constexpr int K2 = 9;
+    constexpr int GB = FX ? 4 : 8;                                           // footprint bytes per channel and cell
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    __shared__ unsigned s_max[2];                                            // FX: bit pattern of gmax, per chunk parity
     double *gs = reinterpret_cast<double *>(smem_raw);                       // [SC][RS]: a wave's 64 cells -> 128 banks
-    xvec *xs = reinterpret_cast<xvec *>(smem_raw + (size_t)a.RS * SC * 8);    // [RS][SC]
+    u64 *gq = reinterpret_cast<u64 *>(smem_raw);                             // FX: [SC/2][RS], channels (2j, 2j+1)
+    xvec *xs = reinterpret_cast<xvec *>(smem_raw + (size_t)a.RS * SC * GB);   // [RS][SC]
     const ddcn_geom &g = a.g;
     const int t = threadIdx.x;
 
@@ -145,10 +158,14 @@ __global__ __launch_bounds__(ST, SC == 4 ? 2 : DDCN_S9_WPS) void col2im_coord_ti
         }
     };
 
-    for (int i = t; i < a.RS * SC; i += ST) gs[i] = 0.0;
+    if (FX) {
+        for (int i = t; i < a.RS * SC / 2; i += ST) gq[i] = 0ull;
+        if (t < 2) s_max[t] = 0u;
+    } else {
+        for (int i = t; i < a.RS * SC; i += ST) gs[i] = 0.0;
+    }
     stage_load(cg0);
     stage_store();
-    __syncthreads();
 
     const unsigned pvo = live ? (unsigned)(p * 4) : SOOB;
     const int nchunks = a.CG / SC;
@@ -160,10 +177,37 @@ __global__ __launch_bounds__(ST, SC == 4 ? 2 : DDCN_S9_WPS) void col2im_coord_ti
         for (int cc = 0; cc < SC; ++cc)
             gcv[k][cc] = __builtin_bit_cast(
                 float, __builtin_amdgcn_raw_buffer_load_b32(rgc, pvo, (unsigned)(((cg0 + cc) * K2 + k) * a.ld * 4), 0));
+    // FX: this thread's largest |value it will add| of the chunk held in gcv -> the workgroup's maximum
+    auto publish_max = [&](int parity) {
+        float m = 0.f;
+#pragma unroll
+        for (int k = 0; k < K2; ++k)
+            if (cell[k] >= 0) {
+#pragma unroll
+                for (int cc = 0; cc < SC; ++cc) {
+                    const float v = fabsf(MOD ? gcv[k][cc] * fm[k] : gcv[k][cc]);
+                    m = (v > m || v != v) ? v : m;                       // NaN wins: it has to reach the flush
+                }
+            }
+        // non-negative floats (and +inf, NaN) order like their bit patterns
+        if (m != 0.f) atomicMax(&s_max[parity], __float_as_uint(m) & 0x7fffffffu);
+    };
+    if (FX) {
+        __syncthreads();            // s_max is zero before anyone publishes
+        publish_max(0);
+    }
+    __syncthreads();
     for (int ch = 0; ch < nchunks; ++ch) {
         const int c0 = cg0 + ch * SC;
         const bool more = ch + 1 < nchunks;
         const unsigned pvn = more ? pvo : SOOB;
+        int fx_e = 0;               // FX: contributions are scaled by 2^(19 - fx_e)
+        bool fx_bad = false;
+        if (FX) {
+            const float gmax = __uint_as_float(s_max[ch & 1]);
+            fx_bad = !(gmax <= 3.0e38f);                                  // inf or NaN in the chunk
+            (void)frexpf(fx_bad ? 1.f : gmax, &fx_e);                     // gmax < 2^fx_e (gmax == 0: nothing is added)
+        }
         // A. the next patch goes in flight
         if (more) stage_load(c0 + SC);
         __builtin_amdgcn_sched_barrier(0);
@@ -179,16 +223,41 @@ __global__ __launch_bounds__(ST, SC == 4 ? 2 : DDCN_S9_WPS) void col2im_coord_ti
                 const xvec a1 = xs[ci], a2 = xs[ci + 1], a3 = xs[ci + a.RW], a4 = xs[ci + a.RW + 1];
                 const float hh = 1.f - lh, hw = 1.f - lw;
                 const float w1 = hh * hw, w2 = hh * lw, w3 = lh * hw, w4 = lh * lw;   // == K:133-140 weights
-                double *c1 = gs + ci, *c3 = gs + ci + a.RW;
+                if (FX) {
+                    float tgs[SC];
 #pragma unroll
-                for (int cc = 0; cc < SC; ++cc) {
-                    const float gc = gcv[k][cc];
-                    S1[k] += gc * a1[cc]; S2[k] += gc * a2[cc]; S3[k] += gc * a3[cc]; S4[k] += gc * a4[cc];
-                    const float tg = MOD ? gc * fm[k] : gc;
-                    atomicAdd(c1 + cc * a.RS, (double)(w1 * tg));
-                    atomicAdd(c1 + cc * a.RS + 1, (double)(w2 * tg));
-                    atomicAdd(c3 + cc * a.RS, (double)(w3 * tg));
-                    atomicAdd(c3 + cc * a.RS + 1, (double)(w4 * tg));
+                    for (int cc = 0; cc < SC; ++cc) {
+                        const float gc = gcv[k][cc];
+                        S1[k] += gc * a1[cc]; S2[k] += gc * a2[cc]; S3[k] += gc * a3[cc]; S4[k] += gc * a4[cc];
+                        tgs[cc] = ldexpf(MOD ? gc * fm[k] : gc, 19 - fx_e);
+                    }
+                    if (!fx_bad) {
+                        u64 *q1 = gq + ci, *q3 = gq + ci + a.RW;
+#pragma unroll
+                        for (int pr = 0; pr < SC / 2; ++pr) {
+                            const float lo = tgs[2 * pr], hi = tgs[2 * pr + 1];
+                            auto pack = [](float wl_, float wh_) -> u64 {
+                                const long long l = (long long)__float2int_rn(wl_), h = (long long)__float2int_rn(wh_);
+                                return (u64)((h << 32) + l);
+                            };
+                            atomicAdd(q1 + pr * a.RS, pack(w1 * lo, w1 * hi));
+                            atomicAdd(q1 + pr * a.RS + 1, pack(w2 * lo, w2 * hi));
+                            atomicAdd(q3 + pr * a.RS, pack(w3 * lo, w3 * hi));
+                            atomicAdd(q3 + pr * a.RS + 1, pack(w4 * lo, w4 * hi));
+                        }
+                    }
+                } else {
+                    double *c1 = gs + ci, *c3 = gs + ci + a.RW;
+#pragma unroll
+                    for (int cc = 0; cc < SC; ++cc) {
+                        const float gc = gcv[k][cc];
+                        S1[k] += gc * a1[cc]; S2[k] += gc * a2[cc]; S3[k] += gc * a3[cc]; S4[k] += gc * a4[cc];
+                        const float tg = MOD ? gc * fm[k] : gc;
+                        atomicAdd(c1 + cc * a.RS, (double)(w1 * tg));
+                        atomicAdd(c1 + cc * a.RS + 1, (double)(w2 * tg));
+                        atomicAdd(c3 + cc * a.RS, (double)(w3 * tg));
+                        atomicAdd(c3 + cc * a.RS + 1, (double)(w4 * tg));
+                    }
                 }
             }
 #pragma unroll
@@ -197,23 +266,57 @@ __global__ __launch_bounds__(ST, SC == 4 ? 2 : DDCN_S9_WPS) void col2im_coord_ti
                     float, __builtin_amdgcn_raw_buffer_load_b32(rgc, pvn, (unsigned)(((c0 + SC + cc) * K2 + k) * a.ld * 4), 0));
             __builtin_amdgcn_sched_barrier(0);
         }
+        if (FX && more) publish_max((ch + 1) & 1);   // gcv now holds the next chunk
         __syncthreads();
 
         // C. flush the footprint (one global atomic per touched in-image cell), re-zero, install the next patch
+        if (FX) {
+            if (t == 0) s_max[ch & 1] = 0u;          // everyone has read it; it is published again two chunks on
+            const float inv = ldexpf(1.f, fx_e - 19);
 #pragma unroll
-        for (int j = 0; j < NCELL; ++j) {
-            const int i = t + ST * j;
-            if (i < a.RS) {
-                double v[SC];
-                bool any = false;
+            for (int j = 0; j < NCELL; ++j) {
+                const int i = t + ST * j;
+                if (i < a.RS) {
+                    u64 wq[SC / 2];
+                    bool any = fx_bad;
 #pragma unroll
-                for (int cc = 0; cc < SC; ++cc) { v[cc] = gs[i + cc * a.RS]; any |= v[cc] != 0.0; }
-                if (any) {
-                    float *dst = gxn + (long)c0 * HW + (soff[j] >> 2);
+                    for (int pr = 0; pr < SC / 2; ++pr) { wq[pr] = gq[i + pr * a.RS]; any |= wq[pr] != 0ull; }
+                    if (any) {
+                        float *dst = gxn + (long)c0 * HW + (soff[j] >> 2);
 #pragma unroll
-                    for (int cc = 0; cc < SC; ++cc) {
-                        gs[i + cc * a.RS] = 0.0;
-                        if (soff[j] != SOOB && v[cc] != 0.0) atomicAdd(dst + cc * HW, (float)v[cc]);
+                        for (int pr = 0; pr < SC / 2; ++pr) {
+                            gq[i + pr * a.RS] = 0ull;
+                            const int lo = (int)(unsigned)wq[pr];
+                            const int hi = (int)(((long long)wq[pr] - (long long)lo) >> 32);
+                            if (soff[j] != SOOB) {
+                                if (fx_bad) {
+                                    atomicAdd(dst + (2 * pr) * HW, __uint_as_float(0x7fc00000u));
+                                    atomicAdd(dst + (2 * pr + 1) * HW, __uint_as_float(0x7fc00000u));
+                                } else {
+                                    if (lo != 0) atomicAdd(dst + (2 * pr) * HW, (float)lo * inv);
+                                    if (hi != 0) atomicAdd(dst + (2 * pr + 1) * HW, (float)hi * inv);
+                                }
+                            }
+                        }
+                    }
+                }
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < NCELL; ++j) {
+                const int i = t + ST * j;
+                if (i < a.RS) {
+                    double v[SC];
+                    bool any = false;
+#pragma unroll
+                    for (int cc = 0; cc < SC; ++cc) { v[cc] = gs[i + cc * a.RS]; any |= v[cc] != 0.0; }
+                    if (any) {
+                        float *dst = gxn + (long)c0 * HW + (soff[j] >> 2);
+#pragma unroll
+                        for (int cc = 0; cc < SC; ++cc) {
+                            gs[i + cc * a.RS] = 0.0;
+                            if (soff[j] != SOOB && v[cc] != 0.0) atomicAdd(dst + cc * HW, (float)v[cc]);
+                        }
                     }
                 }
             }
@@ -325,22 +428,27 @@ int launch_col2im_coord_tile9(const float *gcol, const float *x, const float *of
     const long nwg = (long)a.tiles * a.groups;
     if (nwg > 0x7fffffffL || g.N > 65535) return fail(DDCN_ERR_UNSUPPORTED, "col2im_coord_tile9: grid too large");
     dim3 grid((unsigned)nwg, 1, g.N);
-    const size_t smem = (size_t)a.RS * 12 * SC;
+    // opt-in (read per call so that tests can switch it): 15-25 % faster, grad_input accurate to ~1e-5 instead of ~1e-7
+    const char *env_fx = getenv("DDCN_SCATTER_FX");
+    const bool fx = env_fx && atoi(env_fx) != 0 && SC == 4;
+    const size_t smem = (size_t)a.RS * (fx ? 8 : 12) * SC;
     const int ncell = (a.RS + ST - 1) / ST;
     hipError_t e = hipSuccess;
-#define DDCN_S9_LAUNCH2(MOD, NC, SCV)                                                                            \
+#define DDCN_S9_LAUNCH2(MOD, NC, SCV, FXV)                                                                       \
     do {                                                                                                         \
-        e = hipFuncSetAttribute((const void *)&col2im_coord_tile9_kernel<MOD, NC, SCV>,                          \
+        e = hipFuncSetAttribute((const void *)&col2im_coord_tile9_kernel<MOD, NC, SCV, FXV>,                     \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);                          \
         if (e == hipSuccess)                                                                                     \
-            hipLaunchKernelGGL((col2im_coord_tile9_kernel<MOD, NC, SCV>), grid, dim3(ST), smem, stream, a);      \
+            hipLaunchKernelGGL((col2im_coord_tile9_kernel<MOD, NC, SCV, FXV>), grid, dim3(ST), smem, stream, a); \
     } while (0)
 #define DDCN_S9_LAUNCH(NC)                                                                                       \
     do {                                                                                                         \
-        if (mask && SC == 4) DDCN_S9_LAUNCH2(true, NC, 4);                                                       \
-        else if (mask) DDCN_S9_LAUNCH2(true, NC, 2);                                                             \
-        else if (SC == 4) DDCN_S9_LAUNCH2(false, NC, 4);                                                         \
-        else DDCN_S9_LAUNCH2(false, NC, 2);                                                                      \
+        if (mask && fx) DDCN_S9_LAUNCH2(true, NC, 4, true);                                                      \
+        else if (fx) DDCN_S9_LAUNCH2(false, NC, 4, true);                                                        \
+        else if (mask && SC == 4) DDCN_S9_LAUNCH2(true, NC, 4, false);                                           \
+        else if (mask) DDCN_S9_LAUNCH2(true, NC, 2, false);                                                      \
+        else if (SC == 4) DDCN_S9_LAUNCH2(false, NC, 4, false);                                                  \
+        else DDCN_S9_LAUNCH2(false, NC, 2, false);                                                               \
     } while (0)
     if (ncell <= 2) DDCN_S9_LAUNCH(2);
     else if (ncell <= 4) DDCN_S9_LAUNCH(4);

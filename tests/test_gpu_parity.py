@@ -236,6 +236,25 @@ def test_direct_forward_with_sigmoid_matches_composition(geo):
         assert cases.relerr(got, ref.astype(np.float64)) <= BWD_TOL
 
 
+@pytest.mark.parametrize("c", [cases.MEDIUM_CASES[0], cases.MEDIUM_CASES[1]], ids=lambda c: c["name"])
+def test_fixed_point_scatter_footprint_option(c, monkeypatch):
+    """DDCN_SCATTER_FX=1: the LDS footprint of the backward scatter as packed 32-bit fixed point (ds_add_u64, two
+    channels per atomic).  Same bar as the default path; a NaN in grad_output must still surface in grad_input."""
+    monkeypatch.setenv("DDCN_SCATTER_FX", "1")
+    inp = cases.make_inputs(c)
+    kw = cases.kwargs(c)
+    r = _r32(inp)
+    exp = orc.deform_backward(r["x"], r["offset"], r["mask"], r["weight"], r["gout"], c["bias"], **kw)
+    _, grads = _run_hip(c, inp)
+    for k, e in zip(("gx", "goff", "gmask", "gw"), exp[:4]):
+        if e is not None:
+            assert cases.relerr(grads[k], e) <= BWD_TOL, (k, cases.relerr(grads[k], e))
+    bad = dict(inp, gout=inp["gout"].copy())
+    bad["gout"][0, 0, 2, 3] = np.nan
+    _, grads = _run_hip(c, bad)
+    assert np.isnan(grads["gx"]).any()
+
+
 def _fuzz_cases():
     """Seeded random geometries that steer the launch planners through their branches: strip / 2-D tile im2col, tile9 /
     generic scatter, wide / narrow / idle GEMM tiles, strides, odd sizes, wide and tall maps, large offsets (escapees)."""
@@ -292,8 +311,9 @@ def test_half_and_bfloat16_tensors_are_computed_in_fp32(dtype, tol):
     for got, exp in ((x.grad, egx), (off.grad, egoff), (m.grad, egmask), (w.grad, egw)):
         assert got.dtype == dtype
         assert cases.relerr(got.float().cpu().numpy(), exp) <= tol
-    with pytest.raises(RuntimeError):
-        pkg.modulated_deform_conv(x.double(), off.double(), m.double(), w.double(), None, 1, c["pad"], c["dil"], 1, 1)
+    # double tensors have their own kernels (tests/test_gpu_f64.py); mixing dtypes in one call is refused
+    assert pkg.modulated_deform_conv(x.double(), off.double(), m.double(), w.double(), None, 1, c["pad"], c["dil"], 1,
+                                     1).dtype == torch.float64
     with pytest.raises(RuntimeError):
         pkg.modulated_deform_conv(x.float(), off, m, w, None, 1, c["pad"], c["dil"], 1, 1)   # mixed dtypes
 
@@ -398,8 +418,8 @@ def test_error_behaviour_gpu():
         pkg.deform_conv(x.transpose(2, 3), torch.zeros(2, 18, 5, 5, device=DEV), w, None, 1, 1, 1, 1, 1)
     with pytest.raises(RuntimeError, match="wont match"):       # deform_conv_cuda.cpp:196-198
         pkg.deform_conv(x, torch.zeros(2, 18, 5, 5, device=DEV), w, None, 1, 1, 1, 2, 1)
-    with pytest.raises(RuntimeError, match="float32"):
-        pkg.deform_conv(x.double(), torch.zeros(2, 18, 5, 5, device=DEV).double(), w.double(), None, 1, 1, 1, 1, 1)
+    with pytest.raises(RuntimeError, match="float32"):          # an integer tensor names the dtypes that are served
+        pkg.deform_conv(x.int(), torch.zeros(2, 18, 5, 5, device=DEV).int(), w.int(), None, 1, 1, 1, 1, 1)
     L = _lib.lib()
     g = _lib.Geom(2, 4, 5, 5, 4, 3, 3, 1, 1, 1, 1, 1, 1, 1, 1, 5, 5)
     ws = torch.empty(16, device=DEV)

@@ -32,6 +32,8 @@ __global__ __launch_bounds__(256) void k(float *out, int iters, int region, int 
         if (MODE == 6) atomicAdd((double *)&s[idx & ~1], (double)v);            // ds_add_f64
         if (MODE == 8) atomicAdd((double *)&s[((threadIdx.x + it * 3) * 2) % (region - 2)], (double)v);   // ds_add_f64, lanes on consecutive doubles
         if (MODE == 9) atomicAdd((unsigned *)&s[(threadIdx.x + it * 3) % region], (unsigned)(st & 255));      // ds_add_u32, consecutive
+        if (MODE == 10) atomicAdd((unsigned long long *)&s[idx & ~1], (unsigned long long)(st & 255) << 20);   // ds_add_u64
+        if (MODE == 11) atomicAdd((unsigned long long *)&s[((threadIdx.x + it * 3) * 2) % (region - 2)], (unsigned long long)(st & 255));  // ds_add_u64, consecutive
         if (MODE == 7) {                                                        // 4 CAS loops interleaved (4 corners)
             unsigned *a0 = (unsigned *)&s[idx], *a1 = a0 + 1, *a2 = a0 + 46, *a3 = a0 + 47;
             unsigned o0 = *a0, o1 = *a1, o2 = *a2, o3 = *a3;
@@ -86,6 +88,8 @@ int main()
         run<4>("ds_add_rtn_f32", 2000, 11408, spread);
         run<5>("cas_loop", 2000, 11408, spread);
         run<6>("ds_add_f64", 2000, 11408, spread);
+        run<10>("ds_add_u64", 2000, 11408, spread);
+        run<11>("ds_add_u64 linear", 2000, 11408, spread);
         run<7>("cas_loop_x4 (4 adds)", 2000, 11408, spread);
     }
     return 0;
