@@ -203,6 +203,13 @@ int ddcn_modulated_deform_conv_forward_bf16(const void *x, const void *weight, c
                                             const void *mask, void *out, void *workspace, size_t workspace_bytes,
                                             const ddcn_geom *g, void *stream);
 
+/* The same forward for IEEE half tensors (torch.float16): the reference's half instantiation (K:258) computes in half
+ * throughout; here coordinates and accumulation are fp32 and only the columns and the result are rounded to half.
+ * Same coverage (ddcn_bf16_supported) and workspace (ddcn_workspace_bytes_bf16) as the bf16 entry point. */
+int ddcn_modulated_deform_conv_forward_f16(const void *x, const void *weight, const void *bias, const void *offset,
+                                           const void *mask, void *out, void *workspace, size_t workspace_bytes,
+                                           const ddcn_geom *g, void *stream);
+
 /* ---------------------------------------------------------------- deformable PS-RoI pooling
  * Replaces the reference's second extension, `detseg.ops.dcn.deform_pool_cuda`:
  *   PP = detseg/ops/dcn/deform_pool.py

@@ -463,6 +463,19 @@ int ddcn_modulated_deform_conv_forward_bf16(const void *x, const void *weight, c
     return launch_forward_bf16(x, weight, bias, offset, mask, out, workspace, *g, (hipStream_t)stream);
 }
 
+int ddcn_modulated_deform_conv_forward_f16(const void *x, const void *weight, const void *bias, const void *offset,
+                                           const void *mask, void *out, void *workspace, size_t workspace_bytes,
+                                           const ddcn_geom *g, void *stream)
+{
+    REQUIRE(x); REQUIRE(weight); REQUIRE(offset); REQUIRE(out);
+    TRY(check_geom(g));
+    TRY(bf16_supported(*g));
+    if (!workspace || workspace_bytes < bf16_workspace_bytes(*g))
+        return fail(DDCN_ERR_WORKSPACE, "fp16 workspace of %zu bytes, need %zu", workspace_bytes,
+                    bf16_workspace_bytes(*g));
+    return launch_forward_f16(x, weight, bias, offset, mask, out, workspace, *g, (hipStream_t)stream);
+}
+
 int ddcn_deform_psroi_pool_forward_f32(const float *data, const float *rois, const float *offset, float *out,
                                        float *out_count, const ddcn_roi_geom *g, void *stream)
 {

@@ -34,25 +34,46 @@ namespace {
 
 typedef unsigned short bf16_t;  // storage type at the boundary
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+typedef __attribute__((ext_vector_type(2))) _Float16 f16x2;
+typedef __attribute__((ext_vector_type(2))) float f32x2;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
 
-__device__ __forceinline__ float bf2f(bf16_t v) { return __uint_as_float((unsigned)v << 16); }
-// round to nearest even; NaN stays NaN (quiet bit forced)
-__device__ __forceinline__ unsigned f2bf(float f)
-{
-    const unsigned u = __float_as_uint(f);
-    if ((u & 0x7fffffffu) > 0x7f800000u) return (u >> 16) | 0x40u;
-    return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
-}
-// two floats -> bf16 pair (round to nearest even): one v_cvt_pk_bf16_f32 on gfx950
-typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
-typedef __attribute__((ext_vector_type(2))) float f32x2;
-__device__ __forceinline__ unsigned pack2(float lo, float hi)
-{
-    const f32x2 v = {lo, hi};
-    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
-}
+// The 16-bit format of a call: storage is always unsigned short at the boundary.  one(): element -> float;
+// lo()/hi(): the two elements of a packed register; T::pack2(): two floats -> packed pair, round to nearest even
+// (v_cvt_pk_bf16_f32 / v_cvt_f16_f32 + pack on gfx950); mfma(): one 32x32x16 step with fp32 accumulation.
+struct BF16 {
+    static __device__ __forceinline__ float one(bf16_t v) { return __uint_as_float((unsigned)v << 16); }
+    static __device__ __forceinline__ float lo(unsigned u) { return __uint_as_float(u << 16); }
+    static __device__ __forceinline__ float hi(unsigned u) { return __uint_as_float(u & 0xffff0000u); }
+    static __device__ __forceinline__ unsigned pack2(float a, float b)
+    {
+        const f32x2 v = {a, b};
+        return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
+    }
+    static __device__ __forceinline__ f32x16 mfma(u32x4 a, u32x4 b, f32x16 c)
+    {
+        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c,
+                                                       0, 0, 0);
+    }
+};
+struct F16 {
+    static __device__ __forceinline__ float one(bf16_t v) { return (float)__builtin_bit_cast(_Float16, v); }
+    static __device__ __forceinline__ float lo(unsigned u) { return (float)__builtin_bit_cast(f16x2, u)[0]; }
+    static __device__ __forceinline__ float hi(unsigned u) { return (float)__builtin_bit_cast(f16x2, u)[1]; }
+    static __device__ __forceinline__ unsigned pack2(float a, float b)
+    {
+        const f32x2 v = {a, b};
+        return __builtin_bit_cast(unsigned, __builtin_convertvector(v, f16x2));
+    }
+    static __device__ __forceinline__ f32x16 mfma(u32x4 a, u32x4 b, f32x16 c)
+    {
+        return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c,
+                                                      0, 0, 0);
+    }
+};
 
 struct Bf16Args {
     const bf16_t *x, *offset, *mask, *weight, *bias;
@@ -70,18 +91,18 @@ struct Bf16Args {
 constexpr int IT = 256;  // im2col threads
 
 // w1*a1 + w2*a2 + w3*a3 + w4*a4 for the two bf16 halves of a register pair, rounded back to a bf16 pair
+template <typename T>
 __device__ __forceinline__ unsigned blend_pair(unsigned a1, unsigned a2, unsigned a3, unsigned a4, float w1, float w2,
                                                float w3, float w4)
 {
-    const float lo = w1 * __uint_as_float(a1 << 16) + w2 * __uint_as_float(a2 << 16) + w3 * __uint_as_float(a3 << 16) +
-                     w4 * __uint_as_float(a4 << 16);
-    const float hi = w1 * __uint_as_float(a1 & 0xffff0000u) + w2 * __uint_as_float(a2 & 0xffff0000u) +
-                     w3 * __uint_as_float(a3 & 0xffff0000u) + w4 * __uint_as_float(a4 & 0xffff0000u);
-    return pack2(lo, hi);
+    const float lo = w1 * T::lo(a1) + w2 * T::lo(a2) + w3 * T::lo(a3) + w4 * T::lo(a4);
+    const float hi = w1 * T::hi(a1) + w2 * T::hi(a2) + w3 * T::hi(a3) + w4 * T::hi(a4);
+    return T::pack2(lo, hi);
 }
 
 // One sample position, 8 consecutive channel planes, corners read from global memory (K:569-632 / K:466-496):
 // -> the octet of bf16 samples (mask folded in).
+template <typename T>
 __device__ __forceinline__ u32x4 sample_octet_global(const bf16_t *xb, long HW, int H, int W, float h, float w, float m)
 {
     // K:602-610: zero unless -1 < h < H and -1 < w < W; corners outside the map contribute zero
@@ -103,20 +124,20 @@ __device__ __forceinline__ u32x4 sample_octet_global(const bf16_t *xb, long HW, 
 #pragma unroll
     for (int c = 0; c < 8; ++c) {
         const bf16_t *pl = xb + c * HW;
-        const float x1 = (t && l) ? bf2f(pl[i1]) : 0.f, x2 = (t && r) ? bf2f(pl[i2]) : 0.f;
-        const float x3 = (b && l) ? bf2f(pl[i3]) : 0.f, x4 = (b && r) ? bf2f(pl[i4]) : 0.f;
+        const float x1 = (t && l) ? T::one(pl[i1]) : 0.f, x2 = (t && r) ? T::one(pl[i2]) : 0.f;
+        const float x3 = (b && l) ? T::one(pl[i3]) : 0.f, x4 = (b && r) ? T::one(pl[i4]) : 0.f;
         v[c] = w1 * x1 + w2 * x2 + w3 * x3 + w4 * x4;
     }
     u32x4 o;
-    o.x = pack2(v[0], v[1]);
-    o.y = pack2(v[2], v[3]);
-    o.z = pack2(v[4], v[5]);
-    o.w = pack2(v[6], v[7]);
+    o.x = T::pack2(v[0], v[1]);
+    o.y = T::pack2(v[2], v[3]);
+    o.z = T::pack2(v[4], v[5]);
+    o.w = T::pack2(v[6], v[7]);
     return o;
 }
 
 // K:569-632 with bf16 tensors.  grid = (ceil(P/IT), C/8, N)
-template <bool MOD>
+template <typename T, bool MOD>
 __global__ __launch_bounds__(IT, 4) void im2col_bf16_kernel(const Bf16Args a)
 {
     const int p = blockIdx.x * IT + threadIdx.x;
@@ -133,11 +154,11 @@ __global__ __launch_bounds__(IT, 4) void im2col_bf16_kernel(const Bf16Args a)
 #pragma unroll
     for (int k = 0; k < 9; ++k) {
         const int i = k / 3, j = k % 3;
-        const float oh = bf2f(offb[(long)(2 * k) * a.P]), ow = bf2f(offb[(long)(2 * k + 1) * a.P]);
-        const float m = MOD ? bf2f(maskb[(long)k * a.P]) : 1.f;
+        const float oh = T::one(offb[(long)(2 * k) * a.P]), ow = T::one(offb[(long)(2 * k + 1) * a.P]);
+        const float m = MOD ? T::one(maskb[(long)k * a.P]) : 1.f;
         const float h = (float)(ho * a.sh - a.ph + i * a.dh) + oh;
         const float w = (float)(wo * a.sw - a.pw + j * a.dw) + ow;
-        dst[(long)k * a.P] = sample_octet_global(xb, HW, a.H, a.W, h, w, m);
+        dst[(long)k * a.P] = sample_octet_global<T>(xb, HW, a.H, a.W, h, w, m);
     }
 }
 
@@ -157,7 +178,7 @@ constexpr int TH = 8, TW = 32;
 
 // grid = (tiles * cgroups, 1, N); dynamic LDS = 2 buffers of RS cells x 16 bytes
 // PAIR: the patch is staged two cells per 4-byte load (W even, patch columns start on an even image column)
-template <bool MOD, int NCELL, bool PAIR>
+template <typename T, bool MOD, int NCELL, bool PAIR>
 __global__ __launch_bounds__(IT, 2) void im2col_bf16_tile_kernel(const Bf16Args a)
 {
     extern __shared__ u32x4 patch[];
@@ -182,9 +203,9 @@ __global__ __launch_bounds__(IT, 2) void im2col_bf16_tile_kernel(const Bf16Args 
         const bf16_t *maskb = MOD ? a.mask + ((long)n * a.dg + dgi) * 9 * a.P + p : nullptr;
 #pragma unroll
         for (int k = 0; k < 9; ++k) {
-            roh[k] = live ? bf2f(offb[(long)(2 * k) * a.P]) : 0.f;
-            row_[k] = live ? bf2f(offb[(long)(2 * k + 1) * a.P]) : 0.f;
-            rm[k] = (MOD && live) ? bf2f(maskb[(long)k * a.P]) : 1.f;
+            roh[k] = live ? T::one(offb[(long)(2 * k) * a.P]) : 0.f;
+            row_[k] = live ? T::one(offb[(long)(2 * k + 1) * a.P]) : 0.f;
+            rm[k] = (MOD && live) ? T::one(maskb[(long)k * a.P]) : 1.f;
         }
     }
     // staging: cell i = t + 256 j of the patch -> element offset inside one channel plane, -1 outside the image
@@ -286,10 +307,10 @@ __global__ __launch_bounds__(IT, 2) void im2col_bf16_tile_kernel(const Bf16Args 
                 const float q1 = cell[k] < 0 ? 0.f : w1[k], q2 = cell[k] < 0 ? 0.f : w2[k];
                 const float q3 = cell[k] < 0 ? 0.f : w3[k], q4 = cell[k] < 0 ? 0.f : w4[k];
                 u32x4 o;
-                o.x = blend_pair(a1.x, a2.x, a3.x, a4.x, q1, q2, q3, q4);
-                o.y = blend_pair(a1.y, a2.y, a3.y, a4.y, q1, q2, q3, q4);
-                o.z = blend_pair(a1.z, a2.z, a3.z, a4.z, q1, q2, q3, q4);
-                o.w = blend_pair(a1.w, a2.w, a3.w, a4.w, q1, q2, q3, q4);
+                o.x = blend_pair<T>(a1.x, a2.x, a3.x, a4.x, q1, q2, q3, q4);
+                o.y = blend_pair<T>(a1.y, a2.y, a3.y, a4.y, q1, q2, q3, q4);
+                o.z = blend_pair<T>(a1.z, a2.z, a3.z, a4.z, q1, q2, q3, q4);
+                o.w = blend_pair<T>(a1.w, a2.w, a3.w, a4.w, q1, q2, q3, q4);
                 colp[((long)oc * 9 + k) * a.P] = o;
             }
         }
@@ -303,11 +324,11 @@ __global__ __launch_bounds__(IT, 2) void im2col_bf16_tile_kernel(const Bf16Args 
             if (cell[k] != -1) continue;
             // rare: reload the offsets rather than keep 27 registers alive through the main loop
             const bf16_t *offb = a.offset + ((long)n * a.dg + dgi) * 18 * a.P + p;
-            const float h = (float)(ho * a.sh - a.ph + (k / 3) * a.dh) + bf2f(offb[(long)(2 * k) * a.P]);
-            const float w = (float)(wo * a.sw - a.pw + (k % 3) * a.dw) + bf2f(offb[(long)(2 * k + 1) * a.P]);
-            const float m = MOD ? bf2f(a.mask[(((long)n * a.dg + dgi) * 9 + k) * a.P + p]) : 1.f;
+            const float h = (float)(ho * a.sh - a.ph + (k / 3) * a.dh) + T::one(offb[(long)(2 * k) * a.P]);
+            const float w = (float)(wo * a.sw - a.pw + (k % 3) * a.dw) + T::one(offb[(long)(2 * k + 1) * a.P]);
+            const float m = MOD ? T::one(a.mask[(((long)n * a.dg + dgi) * 9 + k) * a.P + p]) : 1.f;
             for (int oc = 0; oc < nocts; ++oc)
-                colp[((long)oc * 9 + k) * a.P] = sample_octet_global(xb + (long)oc * 8 * HW, HW, a.H, a.W, h, w, m);
+                colp[((long)oc * 9 + k) * a.P] = sample_octet_global<T>(xb + (long)oc * 8 * HW, HW, a.H, a.W, h, w, m);
         }
     }
 }
@@ -324,6 +345,7 @@ __device__ __forceinline__ int xcd_logical(int b, int total)
 }
 
 // grid = (tiles_m * tiles_n, N * groups)
+template <typename T>
 __global__ __launch_bounds__(GT) void gemm_bf16_kernel(const Bf16Args a)
 {
     __shared__ u32x4 As[BM * BK / 8];  // slot(row, chunk) = row*8 + (chunk ^ (row & 7))
@@ -385,23 +407,21 @@ __global__ __launch_bounds__(GT) void gemm_bf16_kernel(const Bf16Args a)
         if (k0 + BK < K) gload(k0 + BK);  // in flight during the MFMAs below
 #pragma unroll
         for (int s = 0; s < BK / 16; ++s) {
-            bf16x8 fa[2], fb[2];
+            u32x4 fa[2], fb[2];
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
                 const int row = wm * 64 + i * 32 + r32;
-                const u32x4 v = As[row * 8 + ((s * 2 + hi) ^ (row & 7))];
-                fa[i] = __builtin_bit_cast(bf16x8, v);
+                fa[i] = As[row * 8 + ((s * 2 + hi) ^ (row & 7))];
             }
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
-                const u32x4 v = Bs[(s * 2 + hi) * BN + wn * 64 + j * 32 + r32];
-                fb[j] = __builtin_bit_cast(bf16x8, v);
+                fb[j] = Bs[(s * 2 + hi) * BN + wn * 64 + j * 32 + r32];
             }
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
                 for (int j = 0; j < 2; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = T::mfma(fa[i], fb[j], acc[i][j]);
         }
     }
 
@@ -414,12 +434,12 @@ __global__ __launch_bounds__(GT) void gemm_bf16_kernel(const Bf16Args a)
         for (int e = 0; e < 16; ++e) {
             const int row = m0 + wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * hi;
             if (row >= M) continue;
-            const float bv = bias ? bf2f(bias[row]) : 0.f;
+            const float bv = bias ? T::one(bias[row]) : 0.f;
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
                 const int col = n0 + wn * 64 + j * 32 + r32;
                 const float v = acc[i][j][e] + bv;
-                if (col < a.P) C[(long)row * a.P + col] = (bf16_t)f2bf(v);
+                if (col < a.P) C[(long)row * a.P + col] = (bf16_t)T::pack2(v, 0.f);
             }
         }
     }
@@ -482,24 +502,25 @@ static bool plan_bf16_tile(Bf16Args &a, const ddcn_geom &g)
     return (long)a.tiles * (g.C / CG) < (1L << 31);
 }
 
-template <bool MOD>
+template <typename T, bool MOD>
 static void run_bf16_tile(const Bf16Args &a, const dim3 &grid, hipStream_t stream)
 {
     const size_t lds = (size_t)2 * a.RS * 16;
     const int ncell = (a.RS + IT - 1) / IT;
     if (a.pair) {
-        if (ncell <= 4) hipLaunchKernelGGL((im2col_bf16_tile_kernel<MOD, 4, true>), grid, dim3(IT), lds, stream, a);
-        else if (ncell <= 6) hipLaunchKernelGGL((im2col_bf16_tile_kernel<MOD, 6, true>), grid, dim3(IT), lds, stream, a);
-        else hipLaunchKernelGGL((im2col_bf16_tile_kernel<MOD, 8, true>), grid, dim3(IT), lds, stream, a);
+        if (ncell <= 4) hipLaunchKernelGGL((im2col_bf16_tile_kernel<T, MOD, 4, true>), grid, dim3(IT), lds, stream, a);
+        else if (ncell <= 6) hipLaunchKernelGGL((im2col_bf16_tile_kernel<T, MOD, 6, true>), grid, dim3(IT), lds, stream, a);
+        else hipLaunchKernelGGL((im2col_bf16_tile_kernel<T, MOD, 8, true>), grid, dim3(IT), lds, stream, a);
     } else {
-        if (ncell <= 4) hipLaunchKernelGGL((im2col_bf16_tile_kernel<MOD, 4, false>), grid, dim3(IT), lds, stream, a);
-        else if (ncell <= 6) hipLaunchKernelGGL((im2col_bf16_tile_kernel<MOD, 6, false>), grid, dim3(IT), lds, stream, a);
-        else hipLaunchKernelGGL((im2col_bf16_tile_kernel<MOD, 8, false>), grid, dim3(IT), lds, stream, a);
+        if (ncell <= 4) hipLaunchKernelGGL((im2col_bf16_tile_kernel<T, MOD, 4, false>), grid, dim3(IT), lds, stream, a);
+        else if (ncell <= 6) hipLaunchKernelGGL((im2col_bf16_tile_kernel<T, MOD, 6, false>), grid, dim3(IT), lds, stream, a);
+        else hipLaunchKernelGGL((im2col_bf16_tile_kernel<T, MOD, 8, false>), grid, dim3(IT), lds, stream, a);
     }
 }
 
-int launch_forward_bf16(const void *x, const void *weight, const void *bias, const void *offset, const void *mask,
-                        void *out, void *ws, const ddcn_geom &g, hipStream_t stream)
+template <typename T>
+static int forward_16(const void *x, const void *weight, const void *bias, const void *offset, const void *mask,
+                      void *out, void *ws, const ddcn_geom &g, hipStream_t stream)
 {
     if (int rc = bf16_supported(g)) return rc;
     Bf16Args a = {};
@@ -515,7 +536,7 @@ int launch_forward_bf16(const void *x, const void *weight, const void *bias, con
     a.tiles_m = (a.Cog + BM - 1) / BM;
     a.tiles_n = (a.P + BN - 1) / BN;
 
-    // weights into the path's k order
+    // weights into the path's k order (a permutation of 16-bit words: the same kernel for both formats)
     bf16_t *wp = (bf16_t *)((char *)ws + col_bytes(g));
     const long wtotal = (long)g.Co * a.Kg;
     hipLaunchKernelGGL(repack_w_kernel, dim3((unsigned)((wtotal + 255) / 256)), dim3(256), 0, stream,
@@ -525,18 +546,30 @@ int launch_forward_bf16(const void *x, const void *weight, const void *bias, con
 
     if (plan_bf16_tile(a, g)) {
         const dim3 grid((unsigned)(a.tiles * (g.C / a.CG)), 1, (unsigned)g.N);
-        if (mask) run_bf16_tile<true>(a, grid, stream);
-        else run_bf16_tile<false>(a, grid, stream);
+        if (mask) run_bf16_tile<T, true>(a, grid, stream);
+        else run_bf16_tile<T, false>(a, grid, stream);
     } else {
         const dim3 ig((unsigned)((a.P + IT - 1) / IT), (unsigned)(g.C / 8), (unsigned)g.N);
-        if (mask) hipLaunchKernelGGL(im2col_bf16_kernel<true>, ig, dim3(IT), 0, stream, a);
-        else hipLaunchKernelGGL(im2col_bf16_kernel<false>, ig, dim3(IT), 0, stream, a);
+        if (mask) hipLaunchKernelGGL((im2col_bf16_kernel<T, true>), ig, dim3(IT), 0, stream, a);
+        else hipLaunchKernelGGL((im2col_bf16_kernel<T, false>), ig, dim3(IT), 0, stream, a);
     }
-    if (int rc = check_launch("im2col_bf16")) return rc;
+    if (int rc = check_launch("im2col_16")) return rc;
     const long tiles = (long)a.tiles_m * a.tiles_n;
-    if (tiles >= (1L << 31)) return fail(DDCN_ERR_UNSUPPORTED, "bf16 path: too many GEMM tiles");
-    hipLaunchKernelGGL(gemm_bf16_kernel, dim3((unsigned)tiles, (unsigned)(g.N * g.groups)), dim3(GT), 0, stream, a);
-    return check_launch("gemm_bf16");
+    if (tiles >= (1L << 31)) return fail(DDCN_ERR_UNSUPPORTED, "16-bit path: too many GEMM tiles");
+    hipLaunchKernelGGL(gemm_bf16_kernel<T>, dim3((unsigned)tiles, (unsigned)(g.N * g.groups)), dim3(GT), 0, stream, a);
+    return check_launch("gemm_16");
+}
+
+int launch_forward_bf16(const void *x, const void *weight, const void *bias, const void *offset, const void *mask,
+                        void *out, void *ws, const ddcn_geom &g, hipStream_t stream)
+{
+    return forward_16<BF16>(x, weight, bias, offset, mask, out, ws, g, stream);
+}
+
+int launch_forward_f16(const void *x, const void *weight, const void *bias, const void *offset, const void *mask,
+                       void *out, void *ws, const ddcn_geom &g, hipStream_t stream)
+{
+    return forward_16<F16>(x, weight, bias, offset, mask, out, ws, g, stream);
 }
 
 }  // namespace ddcn

@@ -70,6 +70,9 @@ int bf16_supported(const ddcn_geom &g);
 int launch_forward_bf16(const void *x, const void *weight, const void *bias, const void *offset, const void *mask,
                         void *out, void *ws, const ddcn_geom &g, hipStream_t stream);
 
+int launch_forward_f16(const void *x, const void *weight, const void *bias, const void *offset, const void *mask,
+                       void *out, void *ws, const ddcn_geom &g, hipStream_t stream);
+
 int launch_psroi_forward(const float *data, const float *rois, const float *trans, float *out, float *out_count,
                          const ddcn_roi_geom *g, hipStream_t stream);
 int launch_psroi_backward(const float *grad_out, const float *data, const float *rois, const float *trans,

@@ -71,6 +71,7 @@ PROTOTYPES = {
     "ddcn_workspace_bytes_bf16": [_G],
     "ddcn_bf16_supported": [_G],
     "ddcn_modulated_deform_conv_forward_bf16": [_P, _P, _P, _P, _P, _P, _P, _SZ, _G, _P],
+    "ddcn_modulated_deform_conv_forward_f16": [_P, _P, _P, _P, _P, _P, _P, _SZ, _G, _P],
     "ddcn_deform_psroi_pool_forward_f32": [_P, _P, _P, _P, _P, _RG, _P],
     "ddcn_deform_psroi_pool_backward_f32": [_P, _P, _P, _P, _P, _P, _P, _RG, _P],
 }

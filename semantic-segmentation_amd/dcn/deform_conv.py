@@ -88,8 +88,8 @@ def _contig(name, t):
 SAVE_COLUMNS = os.environ.get("DDCN_SAVE_COLUMNS", "1") != "0"
 
 
-# Inference on bfloat16 tensors (no tensor of the call requires grad) runs the native bf16 kernels: bf16 columns, MFMA
-# with fp32 accumulation (BASELINE config 5).  DDCN_BF16_NATIVE=0, a geometry they do not cover, or any tensor that
+# Inference on bfloat16 / float16 tensors (no tensor of the call requires grad) runs the native 16-bit kernels: 16-bit
+# columns, MFMA with fp32 accumulation (BASELINE config 5).  DDCN_BF16_NATIVE=0, a geometry they do not cover, or any tensor that
 # requires grad selects the fp32 kernels (convert in, compute, convert out).
 BF16_NATIVE = os.environ.get("DDCN_BF16_NATIVE", "1") != "0"
 
@@ -99,11 +99,13 @@ def _bf16_forward(input, offset, mask, weight, bias, g):
     L = _lib.lib()
     if not BF16_NATIVE or L.ddcn_bf16_supported(g) != 0:
         return None
+    entry = (L.ddcn_modulated_deform_conv_forward_bf16 if input.dtype == torch.bfloat16
+             else L.ddcn_modulated_deform_conv_forward_f16)
     output = input.new_empty((g.N, g.Co, g.Ho, g.Wo))
     nbytes = L.ddcn_workspace_bytes_bf16(g)
-    ws = torch.empty(nbytes // 2, dtype=torch.bfloat16, device=input.device)
+    ws = torch.empty(nbytes // 2, dtype=input.dtype, device=input.device)
     with torch.cuda.device(input.device):
-        _lib.check(L.ddcn_modulated_deform_conv_forward_bf16(
+        _lib.check(entry(
             _lib.ptr(input), _lib.ptr(weight), _lib.ptr(bias), _lib.ptr(offset), _lib.ptr(mask), _lib.ptr(output),
             _lib.ptr(ws), nbytes, g, _lib.current_stream(input.device)))
     return output
@@ -177,7 +179,7 @@ class DeformConvFunction(Function):
         needs_grad = weight.requires_grad or offset.requires_grad or input.requires_grad
         if needs_grad:
             ctx.save_for_backward(input, offset, weight, bias)
-        elif ctx.dtype == torch.bfloat16:
+        elif ctx.dtype in (torch.bfloat16, torch.float16):
             output = _bf16_forward(input, offset, None, weight, bias if ctx.with_bias else None, g)
             if output is not None:
                 return output
@@ -262,7 +264,7 @@ class ModulatedDeformConvFunction(Function):
         needs_grad = weight.requires_grad or mask.requires_grad or offset.requires_grad or input.requires_grad
         if needs_grad:
             ctx.save_for_backward(input, offset, mask, weight, bias)
-        elif ctx.dtype == torch.bfloat16:
+        elif ctx.dtype in (torch.bfloat16, torch.float16):
             output = _bf16_forward(input, offset, mask, weight, bias if ctx.with_bias else None, g)
             if output is not None:
                 return output

@@ -1,11 +1,13 @@
-"""GPU parity of the native bf16 forward (BASELINE config 5: bf16 activations, fp32 accumulation).
+"""GPU parity of the native 16-bit forwards: bf16 (BASELINE config 5: bf16 activations, fp32 accumulation) and fp16
+(same kernels instantiated for IEEE half, the reference's third dtype).
 
 The reference has no bf16 path, so the target is the fp64 oracle evaluated on the same
 bf16-rounded inputs.  Two bars, both written here:
-  * end to end: rel-err := max|a-b| / max|b| <= 1e-2;
-  * tight: against the oracle's columns rounded to bf16 and contracted in fp64 -- what an exact implementation of
-    "bf16 columns, exact accumulation" gives -- every element within one final bf16 rounding (2^-8 relative) plus
-    1e-3 of the tensor's scale for the fp32 accumulation and the few columns whose fp32 sample sits on a bf16 tie.
+  * end to end: rel-err := max|a-b| / max|b| <= 1e-2 for bf16, 2e-3 for fp16;
+  * tight: against the oracle's columns rounded to the format and contracted in fp64 -- what an exact implementation
+    of "16-bit columns, exact accumulation" gives -- every element within one final rounding (2^-8 / 2^-11 relative)
+    plus a quarter of one rounding of the tensor's scale for the fp32 accumulation and the few columns whose fp32
+    sample sits on a rounding tie.
 """
 import ctypes
 import importlib
@@ -35,9 +37,21 @@ BF16_CASES = [
 ]
 
 
+DT = torch.bfloat16   # format under test; the fp16 tests switch it through the `fmt` fixture
+
+
+@pytest.fixture(params=["bf16", "f16"])
+def fmt(request):
+    """(dtype, relative size of one output rounding, end-to-end tolerance)"""
+    global DT
+    DT = torch.bfloat16 if request.param == "bf16" else torch.float16
+    yield (DT, 2.0 ** -8, 1e-2) if request.param == "bf16" else (DT, 2.0 ** -11, 2e-3)
+    DT = torch.bfloat16
+
+
 def _bf(a):
-    """numpy fp64 -> values representable in bf16 (as fp64)."""
-    return torch.from_numpy(np.asarray(a, dtype=np.float32)).bfloat16().double().numpy()
+    """numpy fp64 -> values representable in the 16-bit format under test (as fp64)."""
+    return torch.from_numpy(np.asarray(a, dtype=np.float32)).to(DT).double().numpy()
 
 
 def _inputs(c, seed=0):
@@ -52,7 +66,7 @@ def _inputs(c, seed=0):
 
 
 def _t(a):
-    return None if a is None else torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(DEV).bfloat16()
+    return None if a is None else torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(DEV).to(DT)
 
 
 def _exact_bf16_columns_result(c, x, off, mask, w, bias, Ho, Wo):
@@ -72,7 +86,8 @@ def _exact_bf16_columns_result(c, x, off, mask, w, bias, Ho, Wo):
 
 @pytest.mark.parametrize("tiled", ["1", "0"], ids=["lds_tiled", "direct"])
 @pytest.mark.parametrize("c", BF16_CASES, ids=lambda c: c["name"])
-def test_native_bf16_forward_matches_oracle(c, tiled, monkeypatch):
+def test_native_bf16_forward_matches_oracle(c, tiled, fmt, monkeypatch):
+    dtype, ulp, e2e_tol = fmt
     monkeypatch.setenv("DDCN_BF16_TILE", tiled)   # read by the library at every call
     x, off, mask, w, bias, Ho, Wo = _inputs(c)
     g = _lib.Geom(c["N"], c["C"], c["H"], c["W"], c["Co"], 3, 3, c["stride"], c["stride"], c["pad"], c["pad"],
@@ -84,24 +99,25 @@ def test_native_bf16_forward_matches_oracle(c, tiled, monkeypatch):
             out = pkg.modulated_deform_conv(tx, toff, tmask, tw, tb, c["stride"], c["pad"], c["dil"], c["groups"], c["dg"])
         else:
             out = pkg.deform_conv(tx, toff, tw, tb, c["stride"], c["pad"], c["dil"], c["groups"], c["dg"])
-    assert out.dtype == torch.bfloat16 and out.shape == (c["N"], c["Co"], Ho, Wo)
+    assert out.dtype == dtype and out.shape == (c["N"], c["Co"], Ho, Wo)
 
     # the same call through the C ABI gives the same bits: the Python layer did take the native path
     raw = torch.empty_like(out)
     nbytes = _lib.lib().ddcn_workspace_bytes_bf16(g)
     assert nbytes >= (c["N"] * c["C"] * 9 * Ho * Wo + c["Co"] * c["C"] // c["groups"] * 9) * 2   # columns + repacked weights
-    ws = torch.empty(nbytes // 2, dtype=torch.bfloat16, device=DEV)
-    _lib.check(_lib.lib().ddcn_modulated_deform_conv_forward_bf16(
-        _lib.ptr(tx), _lib.ptr(tw), _lib.ptr(tb), _lib.ptr(toff), _lib.ptr(tmask), _lib.ptr(raw), _lib.ptr(ws), nbytes,
-        g, _lib.current_stream(tx.device)))
+    ws = torch.empty(nbytes // 2, dtype=dtype, device=DEV)
+    entry = (_lib.lib().ddcn_modulated_deform_conv_forward_bf16 if dtype == torch.bfloat16
+             else _lib.lib().ddcn_modulated_deform_conv_forward_f16)
+    _lib.check(entry(_lib.ptr(tx), _lib.ptr(tw), _lib.ptr(tb), _lib.ptr(toff), _lib.ptr(tmask), _lib.ptr(raw),
+                     _lib.ptr(ws), nbytes, g, _lib.current_stream(tx.device)))
     torch.cuda.synchronize()
     assert torch.equal(raw, out)
 
     got = out.double().cpu().numpy()
     exp = orc.deform_forward(x, off, mask, w, bias, c["stride"], c["pad"], c["dil"], c["groups"], c["dg"])
-    assert cases.relerr(got, exp) <= 1e-2, cases.relerr(got, exp)
+    assert cases.relerr(got, exp) <= e2e_tol, cases.relerr(got, exp)
     tight = _exact_bf16_columns_result(c, x, off, mask, w, bias, Ho, Wo)
-    bound = 2.0 ** -8 * np.abs(tight) + 1e-3 * np.abs(tight).max()
+    bound = ulp * np.abs(tight) + 4 * ulp * 0.0625 * np.abs(tight).max()
     assert np.all(np.abs(got - tight) <= bound), float((np.abs(got - tight) / bound).max())
 
 
