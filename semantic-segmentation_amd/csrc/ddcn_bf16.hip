@@ -445,6 +445,147 @@ __global__ __launch_bounds__(GT) void gemm_bf16_kernel(const Bf16Args a)
     }
 }
 
+
+// ---------------------------------------------------------------- GEMM, LDS-DMA variant
+// Same tiles and fragments as gemm_bf16_kernel, but the operands go global -> LDS directly (buffer_load_dwordx4 ... lds)
+// through a ring of NS stages of 32 k each: no staging registers (the kernel fits 4 workgroups on a CU), no second
+// barrier, and a tile request has NS-1 K steps to arrive.  One iteration: wait for this wave's requests of tile kt
+// (counted vmcnt: the younger tiles may stay in flight), barrier (everyone's part of tile kt has landed AND everyone
+// is done reading tile kt-1), request tile kt+NS-1 into the stage tile kt-1 occupied, MFMAs on tile kt.
+// The DMA places lane l's 16 bytes at (stage base + l*16), so the XOR swizzle of the W rows is applied to the
+// global address each lane fetches from; out-of-range chunks are fetched through an out-of-range offset and land
+// as zeros.
+typedef __attribute__((address_space(3))) void lds_void;
+constexpr int DK = 32;
+constexpr unsigned DMA_OOB = 0x80000000u;
+
+// A descriptor the compiler knows to be wave-uniform (otherwise every DMA request is wrapped in a waterfall loop)
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t uniform_rsrc(const void *p, unsigned bytes)
+{
+    const unsigned long long v = (unsigned long long)p;
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v);
+    const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+    return __builtin_amdgcn_make_buffer_rsrc((void *)(((unsigned long long)hi << 32) | lo), 0,
+                                             __builtin_amdgcn_readfirstlane(bytes), 0x00020000);
+}
+
+// MI = 32-row MFMA tiles per wave along M: 2 -> 128-row workgroup tile (64x64 per wave, one fragment read per MFMA),
+// 4 -> 256-row tile (128x64 per wave: 6 fragment reads per 8 MFMAs, the LDS pipe stops being the co-bottleneck).
+constexpr unsigned wait_vm_lgkm0(int vm) { return (unsigned)((vm & 0xF) | ((vm >> 4) << 14) | 0x0070); }
+
+template <typename T, int NS, int MI>
+__global__ __launch_bounds__(GT, MI == 4 ? 2 : (NS == 2 ? 4 : (NS == 3 ? 3 : 2))) void gemm16_dma_kernel(const Bf16Args a)
+{
+    constexpr int BMK = 2 * MI * 32;              // rows of the workgroup tile
+    constexpr int RA = BMK * 4 / GT;              // A requests per thread and stage (B: 2)
+    constexpr int STAGE = BMK * 4 + 512;          // 16-byte chunks per stage
+    extern __shared__ u32x4 ring[];   // NS stages of [A: BMK rows x 4 chunks][B: 4 octets x 128 pixels]
+    const int t = threadIdx.x, lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);   // uniform: the DMA's LDS base goes through M0
+    const int wm = wave >> 1, wn = wave & 1;
+    const int tiles_m = (a.Cog + BMK - 1) / BMK;
+    const int L = xcd_logical(blockIdx.x, tiles_m * a.tiles_n);
+    const int m0 = (L % tiles_m) * BMK, n0 = (L / tiles_m) * BN;
+    const int img = blockIdx.y / a.groups, grp = blockIdx.y % a.groups;
+    const int M = a.Cog, K = a.Kg, KOg = K / 8;
+
+    const __amdgpu_buffer_rsrc_t rA = uniform_rsrc(a.weight + (long)grp * M * K, (unsigned)((long)M * K * 2));
+    const __amdgpu_buffer_rsrc_t rB = uniform_rsrc((const u32x4 *)a.col + ((long)img * a.KO + (long)grp * KOg) * a.P,
+                                                   (unsigned)((long)KOg * a.P * 16));
+
+    // this thread's RA chunks of A and two of B per stage; request r of wave w fills ring chunks (r*4+w)*64 + lane
+    unsigned offA[RA], offB[2];
+    int kcA[RA];
+#pragma unroll
+    for (int r = 0; r < RA; ++r) {
+        const int q = (r * 4 + wave) * 64 + lane;
+        const int row = q >> 2, c = (q & 3) ^ ((row >> 2) & 3);
+        kcA[r] = c * 8;
+        offA[r] = (m0 + row < M) ? (unsigned)(((m0 + row) * K + c * 8) * 2) : DMA_OOB;
+    }
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        const int q = (r * 4 + wave) * 64 + lane;
+        const int oct = q >> 7, nn = n0 + (q & 127);
+        offB[r] = (nn < a.P) ? (unsigned)((oct * a.P + nn) * 16) : DMA_OOB;
+    }
+    auto request = [&](int kt) {
+        const int st = kt % NS, k0 = kt * DK;
+        char *base = (char *)(ring + st * STAGE) + wave * 1024;
+#pragma unroll
+        for (int r = 0; r < RA; ++r) {
+            const unsigned va = (offA[r] != DMA_OOB && k0 + kcA[r] < K) ? offA[r] + (unsigned)(k0 * 2) : DMA_OOB;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, (lds_void *)(base + r * 4096), 16, va, 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            const unsigned vb = offB[r] != DMA_OOB ? offB[r] + (unsigned)((k0 / 8) * a.P * 16) : DMA_OOB;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rB, (lds_void *)(base + BMK * 64 + r * 4096), 16, vb, 0, 0, 0);
+        }
+    };
+
+    f32x16 acc[MI][2];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    const int r32 = lane & 31, hi = lane >> 5;
+    const int ntiles = (K + DK - 1) / DK;
+#pragma unroll
+    for (int kt = 0; kt < NS - 1; ++kt)
+        if (kt < ntiles) request(kt);
+    for (int kt = 0; kt < ntiles; ++kt) {
+        // younger tiles still allowed in flight: RA + 2 requests each
+        const int rem = min(NS - 2, ntiles - 1 - kt);
+        // one s_waitcnt: this wave's LDS reads of tile kt-1 are done (lgkmcnt 0) and its requests of tile kt have
+        // landed (vmcnt counts the requests that may stay in flight).  A plain __syncthreads() would drain vmcnt to 0.
+        if (rem >= 2) __builtin_amdgcn_s_waitcnt(wait_vm_lgkm0(2 * (RA + 2)));
+        else if (rem == 1) __builtin_amdgcn_s_waitcnt(wait_vm_lgkm0(RA + 2));
+        else __builtin_amdgcn_s_waitcnt(wait_vm_lgkm0(0));
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        if (kt + NS - 1 < ntiles) request(kt + NS - 1);
+        const u32x4 *As = ring + (kt % NS) * STAGE, *Bs = As + BMK * 4;
+#pragma unroll
+        for (int s = 0; s < DK / 16; ++s) {
+            u32x4 fa[MI], fb[2];
+#pragma unroll
+            for (int i = 0; i < MI; ++i) {
+                const int row = wm * (MI * 32) + i * 32 + r32;
+                fa[i] = As[row * 4 + ((s * 2 + hi) ^ ((row >> 2) & 3))];
+            }
+#pragma unroll
+            for (int j = 0; j < 2; ++j) fb[j] = Bs[(s * 2 + hi) * BN + wn * 64 + j * 32 + r32];
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] = T::mfma(fa[i], fb[j], acc[i][j]);
+        }
+    }
+
+    bf16_t *C = a.out + ((long)img * a.Co + (long)grp * M) * a.P;
+    const bf16_t *bias = a.bias ? a.bias + grp * M : nullptr;
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int row = m0 + wm * (MI * 32) + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * hi;
+            if (row >= M) continue;
+            const float bv = bias ? T::one(bias[row]) : 0.f;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int col = n0 + wn * 64 + j * 32 + r32;
+                const float v = acc[i][j][e] + bv;
+                if (col < a.P) C[(long)row * a.P + col] = (bf16_t)T::pack2(v, 0.f);
+            }
+        }
+    }
+}
+
 }  // namespace
 
 static size_t col_bytes(const ddcn_geom &g)
@@ -556,7 +697,30 @@ static int forward_16(const void *x, const void *weight, const void *bias, const
     if (int rc = check_launch("im2col_16")) return rc;
     const long tiles = (long)a.tiles_m * a.tiles_n;
     if (tiles >= (1L << 31)) return fail(DDCN_ERR_UNSUPPORTED, "16-bit path: too many GEMM tiles");
-    hipLaunchKernelGGL(gemm_bf16_kernel<T>, dim3((unsigned)tiles, (unsigned)(g.N * g.groups)), dim3(GT), 0, stream, a);
+    const dim3 ggrid((unsigned)tiles, (unsigned)(g.N * g.groups));
+    // LDS-DMA ring (default 4 stages); DDCN_BF16_GEMM_STAGES=0 selects the register-staged kernel.  The DMA kernel
+    // addresses W and one (image, group) columns slab with 31-bit byte offsets.
+    const char *es = getenv("DDCN_BF16_GEMM_STAGES");
+    const int stages = es ? atoi(es) : 4;
+    const bool dma_ok = (long)a.Cog * a.Kg * 2 < (1L << 31) && (long)(a.Kg / 8) * a.P * 16 < (1L << 31);
+    // 256-row tiles (128x64 per wave) when Co fills them and they still give every CU two workgroups; DDCN_BF16_GEMM_MI forces 2 or 4
+    const char *em = getenv("DDCN_BF16_GEMM_MI");
+    const long tiles256 = (long)((a.Cog + 255) / 256) * a.tiles_n * g.N * g.groups;
+    const int mi = em ? atoi(em) : ((a.Cog >= 192 && tiles256 >= 512) ? 4 : 2);
+    if (dma_ok && mi == 4 && stages >= 2) {
+        const dim3 g4((unsigned)((a.Cog + 255) / 256 * a.tiles_n), (unsigned)(g.N * g.groups));
+        static bool attr = false;   // 3 stages x 24 KiB: above the 64 KiB default
+        if (!attr) {
+            if (hipFuncSetAttribute((const void *)gemm16_dma_kernel<T, 3, 4>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    3 * 24576) != hipSuccess)
+                return fail(DDCN_ERR_LAUNCH, "gemm_16: cannot raise the LDS limit");
+            attr = true;
+        }
+        hipLaunchKernelGGL((gemm16_dma_kernel<T, 3, 4>), g4, dim3(GT), 3 * 24576, stream, a);
+    } else if (dma_ok && stages == 2) hipLaunchKernelGGL((gemm16_dma_kernel<T, 2, 2>), ggrid, dim3(GT), 2 * 16384, stream, a);
+    else if (dma_ok && stages == 3) hipLaunchKernelGGL((gemm16_dma_kernel<T, 3, 2>), ggrid, dim3(GT), 3 * 16384, stream, a);
+    else if (dma_ok && stages >= 4) hipLaunchKernelGGL((gemm16_dma_kernel<T, 4, 2>), ggrid, dim3(GT), 4 * 16384, stream, a);
+    else hipLaunchKernelGGL(gemm_bf16_kernel<T>, ggrid, dim3(GT), 0, stream, a);
     return check_launch("gemm_16");
 }
 

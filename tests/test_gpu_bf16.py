@@ -84,11 +84,17 @@ def _exact_bf16_columns_result(c, x, off, mask, w, bias, Ho, Wo):
     return out.reshape(c["N"], c["Co"], Ho, Wo)
 
 
-@pytest.mark.parametrize("tiled", ["1", "0"], ids=["lds_tiled", "direct"])
+@pytest.mark.parametrize("tiled", ["1", "0", "mi4", "regstage"], ids=["lds_tiled", "direct", "gemm_256_rows", "gemm_regstage"])
 @pytest.mark.parametrize("c", BF16_CASES, ids=lambda c: c["name"])
 def test_native_bf16_forward_matches_oracle(c, tiled, fmt, monkeypatch):
     dtype, ulp, e2e_tol = fmt
-    monkeypatch.setenv("DDCN_BF16_TILE", tiled)   # read by the library at every call
+    # read by the library at every call: im2col kernel (LDS-tiled / direct gather) and GEMM variant (LDS-DMA ring with
+    # 128- or 256-row tiles, register-staged)
+    monkeypatch.setenv("DDCN_BF16_TILE", "0" if tiled == "0" else "1")
+    if tiled == "mi4":
+        monkeypatch.setenv("DDCN_BF16_GEMM_MI", "4")
+    if tiled == "regstage":
+        monkeypatch.setenv("DDCN_BF16_GEMM_STAGES", "0")
     x, off, mask, w, bias, Ho, Wo = _inputs(c)
     g = _lib.Geom(c["N"], c["C"], c["H"], c["W"], c["Co"], 3, 3, c["stride"], c["stride"], c["pad"], c["pad"],
                   c["dil"], c["dil"], c["groups"], c["dg"], Ho, Wo)
