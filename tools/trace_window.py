@@ -16,7 +16,7 @@ def main():
     tot = sum(e[1] - e[0] for e in sel)
     d = collections.defaultdict(lambda: [0, 0])
     for s, e, n in sel:
-        key = ("ddcn:" + n.split("ddcn::")[-1].replace("(anonymous namespace)::", "").split("(")[0][:44]
+        key = ("ddcn:" + n.replace("(anonymous namespace)::", "").split("ddcn::")[1].split("(")[0][:44]
                if "ddcn::" in n else n[:64])
         d[key][0] += e - s
         d[key][1] += 1
