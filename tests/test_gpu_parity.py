@@ -147,6 +147,10 @@ GEMM_CASES = [
     cases.C("gemm_tail_c4_257x257", N=1, Ci=4, Co=72, H=257, W=257, pad=1, dil=1, seed=60),
     # 3 row tiles x 2 images: odd tile counts in the wide class
     cases.C("gemm_odd_c8_150x150", N=2, Ci=8, Co=300, H=150, W=150, pad=1, dil=1, seed=61),
+    # few output channels (the DDCN mask branch): the backward contractions run as bandwidth kernels (ddcn_skinny.hip);
+    # K = 360 and K = 63 leave partial row blocks, 97 x 97 pixels split over several workgroups
+    cases.C("skinny_co9_c40_97x97", N=3, Ci=40, Co=9, H=97, W=97, pad=2, dil=2, seed=62),
+    cases.C("skinny_co12_c7_33x21", N=2, Ci=7, Co=12, H=33, W=21, pad=1, dil=1, seed=63),
 ]
 
 
