@@ -477,6 +477,32 @@ def test_full_size_config1_against_oracle_one_image():
     assert cases.relerr(wd.grad.cpu().numpy(), egw) <= BWD_TOL
 
 
+@pytest.mark.parametrize("name,C,H,stride,dil", [
+    ("r101_layer2_block0", 128, 193, 2, 1),    # the strided DDCN layer: 193^2 -> 97^2
+    ("r101_layer3_block1", 256, 97, 1, 2),     # the shape 23 of the 30 layers of DDCN-R101 run at
+], ids=lambda v: v if isinstance(v, str) else None)
+def test_full_size_model_layer_shapes_against_oracle(name, C, H, stride, dil):
+    """One image of the DDCN-ResNet101 layer shapes that differ from the config 1 layer, against the fp64 oracle."""
+    gen = torch.Generator(device="cpu").manual_seed(7)
+    Ho = (H + 2 * dil - (2 * dil + 1)) // stride + 1
+    x = torch.randn(1, C, H, H, generator=gen)
+    w = (torch.rand(C, C, 3, 3, generator=gen) * 2 - 1) / ((C * 9) ** 0.5)
+    off = (torch.floor(torch.randn(1, 18, Ho, Ho, generator=gen) * 2 * 1024) + 0.5) / 1024
+    mask = torch.sigmoid(torch.randn(1, 9, Ho, Ho, generator=gen))
+    gout = torch.randn(1, C, Ho, Ho, generator=gen)
+    xd, wd, od, md = (t.to(DEV).requires_grad_(True) for t in (x, w, off, mask))
+    out = pkg.modulated_deform_conv(xd, od, md, wd, None, stride, dil, dil, 1, 1)
+    assert out.shape == (1, C, Ho, Ho)
+    out.backward(gout.to(DEV))
+    f64 = lambda t: t.numpy().astype(np.float64)
+    eout = orc.deform_forward(f64(x), f64(off), f64(mask), f64(w), None, stride, dil, dil, 1, 1)
+    egx, egoff, egmask, egw, _ = orc.deform_backward(f64(x), f64(off), f64(mask), f64(w), f64(gout), False, stride, dil,
+                                                     dil, 1, 1)
+    assert cases.relerr(out.detach().cpu().numpy(), eout) <= FWD_TOL
+    for got, exp in ((xd.grad, egx), (od.grad, egoff), (md.grad, egmask), (wd.grad, egw)):
+        assert cases.relerr(got.cpu().numpy(), exp) <= BWD_TOL
+
+
 def test_full_size_config1_properties():
     """Size-independent properties at BASELINE config 1 (N=2): zero offsets + unit mask == dilated conv2d;
     linearity in the weight; gradient of sum(out) w.r.t. bias-free weight equals the summed columns identity
