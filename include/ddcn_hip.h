@@ -245,6 +245,14 @@ int ddcn_deform_psroi_pool_backward_f32(const float *grad_out, const float *data
                                         const float *offset, const float *out_count, float *grad_data,
                                         float *grad_offset, const ddcn_roi_geom *g, void *stream);
 
+/* The same two entry points for double tensors (the reference instantiates its pooling kernels for every floating
+ * type, PK:293 / PK:342); used by the fp64 gradcheck of the pooling operator. */
+int ddcn_deform_psroi_pool_forward_f64(const double *data, const double *rois, const double *offset, double *out,
+                                       double *out_count, const ddcn_roi_geom *g, void *stream);
+int ddcn_deform_psroi_pool_backward_f64(const double *grad_out, const double *data, const double *rois,
+                                        const double *offset, const double *out_count, double *grad_data,
+                                        double *grad_offset, const ddcn_roi_geom *g, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -490,4 +490,18 @@ int ddcn_deform_psroi_pool_backward_f32(const float *grad_out, const float *data
                                  (hipStream_t)stream);
 }
 
+int ddcn_deform_psroi_pool_forward_f64(const double *data, const double *rois, const double *offset, double *out,
+                                       double *out_count, const ddcn_roi_geom *g, void *stream)
+{
+    return launch_psroi_forward_f64(data, rois, offset, out, out_count, g, (hipStream_t)stream);
+}
+
+int ddcn_deform_psroi_pool_backward_f64(const double *grad_out, const double *data, const double *rois,
+                                        const double *offset, const double *out_count, double *grad_data,
+                                        double *grad_offset, const ddcn_roi_geom *g, void *stream)
+{
+    return launch_psroi_backward_f64(grad_out, data, rois, offset, out_count, grad_data, grad_offset, g,
+                                     (hipStream_t)stream);
+}
+
 }  // extern "C"

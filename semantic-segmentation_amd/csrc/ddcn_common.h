@@ -79,4 +79,10 @@ int launch_psroi_backward(const float *grad_out, const float *data, const float 
                           const float *out_count, float *grad_data, float *grad_trans, const ddcn_roi_geom *g,
                           hipStream_t stream);
 
+int launch_psroi_forward_f64(const double *data, const double *rois, const double *trans, double *out,
+                             double *out_count, const ddcn_roi_geom *g, hipStream_t stream);
+int launch_psroi_backward_f64(const double *grad_out, const double *data, const double *rois, const double *trans,
+                              const double *out_count, double *grad_data, double *grad_trans, const ddcn_roi_geom *g,
+                              hipStream_t stream);
+
 }  // namespace ddcn

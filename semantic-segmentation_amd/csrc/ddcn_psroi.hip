@@ -27,64 +27,70 @@ namespace {
 constexpr int RT = 256;          // threads per workgroup, both kernels
 constexpr int MAX_BINS = 1024;   // pooled^2 and part^2 limits of the backward kernel (LDS tables)
 
+// T = float or double: the reference instantiates both kernels for every floating type (PK:293, PK:342)
+template <typename T>
 struct RoiArgs {
-    const float *data, *rois, *trans, *cnt, *gout;
-    float *out, *out_cnt, *gdata, *gtrans;
+    const T *data, *rois, *trans, *cnt, *gout;
+    T *out, *out_cnt, *gdata, *gtrans;
     int B, C, H, W, R, OC, PS, GS, PART, SPP, NCLS, CEC, no_trans;
-    float scale, tstd;
+    T scale, tstd;
     int chunk;  // backward: channels per workgroup
 };
 
+template <typename T>
 struct RoiBox {
-    float x0, y0, w, h;  // roi_start_w, roi_start_h, roi_width, roi_height
+    T x0, y0, w, h;  // roi_start_w, roi_start_h, roi_width, roi_height
     int batch;
 };
 
 // PK:79-89
-__device__ __forceinline__ RoiBox roi_box(const float *roi, float scale)
+template <typename T>
+__device__ __forceinline__ RoiBox<T> roi_box(const T *roi, T scale)
 {
 #pragma clang fp contract(off)
-    RoiBox b;
+    RoiBox<T> b;
     b.batch = (int)roi[0];
-    b.x0 = roundf(roi[1]) * scale - 0.5f;
-    b.y0 = roundf(roi[2]) * scale - 0.5f;
-    const float x1 = (roundf(roi[3]) + 1.f) * scale - 0.5f;
-    const float y1 = (roundf(roi[4]) + 1.f) * scale - 0.5f;
+    b.x0 = round(roi[1]) * scale - T(0.5);
+    b.y0 = round(roi[2]) * scale - T(0.5);
+    const T x1 = (round(roi[3]) + T(1)) * scale - T(0.5);
+    const T y1 = (round(roi[4]) + T(1)) * scale - T(0.5);
     // the reference compares against the DOUBLE literal 0.1
-    b.w = (float)fmax((double)(x1 - b.x0), 0.1);
-    b.h = (float)fmax((double)(y1 - b.y0), 0.1);
+    b.w = (T)fmax((double)(x1 - b.x0), 0.1);
+    b.h = (T)fmax((double)(y1 - b.y0), 0.1);
     return b;
 }
 
+template <typename T>
 struct BinGeom {
-    float wstart, hstart;
+    T wstart, hstart;
     int gofs;   // gh * GS + gw
     int pidx;   // part_h * PART + part_w
 };
 
 // PK:92-114 for one bin of one (RoI, class)
-__device__ __forceinline__ BinGeom bin_geom(const RoiArgs &a, const RoiBox &b, int n, int cls, int ph, int pw)
+template <typename T>
+__device__ __forceinline__ BinGeom<T> bin_geom(const RoiArgs<T> &a, const RoiBox<T> &b, int n, int cls, int ph, int pw)
 {
 #pragma clang fp contract(off)
-    BinGeom g;
-    const float bin_h = b.h / (float)a.PS, bin_w = b.w / (float)a.PS;
-    const int part_h = (int)floorf((float)ph / (float)a.PS * (float)a.PART);
-    const int part_w = (int)floorf((float)pw / (float)a.PS * (float)a.PART);
+    BinGeom<T> g;
+    const T bin_h = b.h / (T)a.PS, bin_w = b.w / (T)a.PS;
+    const int part_h = (int)floor((T)ph / (T)a.PS * (T)a.PART);
+    const int part_w = (int)floor((T)pw / (T)a.PS * (T)a.PART);
     g.pidx = part_h * a.PART + part_w;
-    float tx = 0.f, ty = 0.f;
+    T tx = T(0), ty = T(0);
     if (!a.no_trans) {
-        const float *t = a.trans + ((long)n * a.NCLS + cls) * 2 * a.PART * a.PART;
+        const T *t = a.trans + ((long)n * a.NCLS + cls) * 2 * a.PART * a.PART;
         tx = t[g.pidx] * a.tstd;
         ty = t[a.PART * a.PART + g.pidx] * a.tstd;
     }
-    float wstart = (float)pw * bin_w + b.x0;
+    T wstart = (T)pw * bin_w + b.x0;
     wstart += tx * b.w;
-    float hstart = (float)ph * bin_h + b.y0;
+    T hstart = (T)ph * bin_h + b.y0;
     hstart += ty * b.h;
     g.wstart = wstart;
     g.hstart = hstart;
-    int gw = (int)floorf((float)pw * (float)a.GS / (float)a.PS);
-    int gh = (int)floorf((float)ph * (float)a.GS / (float)a.PS);
+    int gw = (int)floor((T)pw * (T)a.GS / (T)a.PS);
+    int gh = (int)floor((T)ph * (T)a.GS / (T)a.PS);
     gw = min(max(gw, 0), a.GS - 1);
     gh = min(max(gh, 0), a.GS - 1);
     g.gofs = gh * a.GS + gw;
@@ -92,15 +98,17 @@ __device__ __forceinline__ BinGeom bin_geom(const RoiArgs &a, const RoiBox &b, i
 }
 
 // PK:121-128: false when the sample is dropped; otherwise w, h clamped into the map
-__device__ __forceinline__ bool keep_sample(float &w, float &h, int W, int H)
+template <typename T>
+__device__ __forceinline__ bool keep_sample(T &w, T &h, int W, int H)
 {
-    if (w < -0.5f || w > (float)W - 0.5f || h < -0.5f || h > (float)H - 0.5f) return false;
-    w = fminf(fmaxf(w, 0.f), (float)W - 1.f);
-    h = fminf(fmaxf(h, 0.f), (float)H - 1.f);
+    if (w < -T(0.5) || w > (T)W - T(0.5) || h < -T(0.5) || h > (T)H - T(0.5)) return false;
+    w = fmin(fmax(w, T(0)), (T)W - T(1));
+    h = fmin(fmax(h, T(0)), (T)H - T(1));
     return true;
 }
 
-__global__ __launch_bounds__(RT) void psroi_forward_kernel(const RoiArgs a)
+template <typename T>
+__global__ __launch_bounds__(RT) void psroi_forward_kernel(const RoiArgs<T> a)
 {
     const long total = (long)a.R * a.OC * a.PS * a.PS;
     for (long index = (long)blockIdx.x * RT + threadIdx.x; index < total; index += (long)gridDim.x * RT) {
@@ -108,116 +116,117 @@ __global__ __launch_bounds__(RT) void psroi_forward_kernel(const RoiArgs a)
         const int ph = (int)(index / a.PS % a.PS);
         const int ctop = (int)(index / ((long)a.PS * a.PS) % a.OC);
         const int n = (int)(index / ((long)a.PS * a.PS * a.OC));
-        const RoiBox b = roi_box(a.rois + (long)n * 5, a.scale);
-        float sum = 0.f;
+        const RoiBox<T> b = roi_box(a.rois + (long)n * 5, a.scale);
+        T sum = T(0);
         int count = 0;
         if (b.batch >= 0 && b.batch < a.B) {  // a RoI naming an image the batch lacks pools nothing
-            const BinGeom g = bin_geom(a, b, n, ctop / a.CEC, ph, pw);
-            float sub_w, sub_h;
+            const BinGeom<T> g = bin_geom(a, b, n, ctop / a.CEC, ph, pw);
+            T sub_w, sub_h;
             {
 #pragma clang fp contract(off)
-                sub_h = b.h / (float)a.PS / (float)a.SPP;
-                sub_w = b.w / (float)a.PS / (float)a.SPP;
+                sub_h = b.h / (T)a.PS / (T)a.SPP;
+                sub_w = b.w / (T)a.PS / (T)a.SPP;
             }
-            const float *plane = a.data + ((long)b.batch * a.C + (long)ctop * a.GS * a.GS + g.gofs) * a.H * a.W;
+            const T *plane = a.data + ((long)b.batch * a.C + (long)ctop * a.GS * a.GS + g.gofs) * a.H * a.W;
             for (int ih = 0; ih < a.SPP; ++ih) {
                 for (int iw = 0; iw < a.SPP; ++iw) {
-                    float w, h;
+                    T w, h;
                     {
 #pragma clang fp contract(off)
-                        w = g.wstart + (float)iw * sub_w;
-                        h = g.hstart + (float)ih * sub_h;
+                        w = g.wstart + (T)iw * sub_w;
+                        h = g.hstart + (T)ih * sub_h;
                     }
                     if (!keep_sample(w, h, a.W, a.H)) continue;
                     // PK:33-50
-                    const int x1 = (int)floorf(w), x2 = (int)ceilf(w);
-                    const int y1 = (int)floorf(h), y2 = (int)ceilf(h);
-                    const float dx = w - (float)x1, dy = h - (float)y1;
-                    const float v11 = plane[y1 * a.W + x1], v12 = plane[y2 * a.W + x1];
-                    const float v21 = plane[y1 * a.W + x2], v22 = plane[y2 * a.W + x2];
-                    sum += (1.f - dx) * (1.f - dy) * v11 + (1.f - dx) * dy * v12 + dx * (1.f - dy) * v21 +
+                    const int x1 = (int)floor(w), x2 = (int)ceil(w);
+                    const int y1 = (int)floor(h), y2 = (int)ceil(h);
+                    const T dx = w - (T)x1, dy = h - (T)y1;
+                    const T v11 = plane[y1 * a.W + x1], v12 = plane[y2 * a.W + x1];
+                    const T v21 = plane[y1 * a.W + x2], v22 = plane[y2 * a.W + x2];
+                    sum += (T(1) - dx) * (T(1) - dy) * v11 + (T(1) - dx) * dy * v12 + dx * (T(1) - dy) * v21 +
                            dx * dy * v22;
                     ++count;
                 }
             }
         }
-        a.out[index] = count == 0 ? 0.f : sum / (float)count;
-        a.out_cnt[index] = (float)count;
+        a.out[index] = count == 0 ? T(0) : sum / (T)count;
+        a.out_cnt[index] = (T)count;
     }
 }
 
 // Adds the pending cell (base pixel p, its right/lower neighbours at +sx / +sy) to the feature gradient.
-__device__ __forceinline__ void flush_cell(float *gplane, int p, int sx, int sy, float a00, float a01, float a10,
-                                           float a11)
+template <typename T>
+__device__ __forceinline__ void flush_cell(T *gplane, int p, int sx, int sy, T a00, T a01, T a10,
+                                           T a11)
 {
-    if (a00 != 0.f) atomicAdd(gplane + p, a00);
-    if (a01 != 0.f) atomicAdd(gplane + p + sy, a01);
-    if (a10 != 0.f) atomicAdd(gplane + p + sx, a10);
-    if (a11 != 0.f) atomicAdd(gplane + p + sx + sy, a11);
+    if (a00 != T(0)) atomicAdd(gplane + p, a00);
+    if (a01 != T(0)) atomicAdd(gplane + p + sy, a01);
+    if (a10 != T(0)) atomicAdd(gplane + p + sx, a10);
+    if (a11 != T(0)) atomicAdd(gplane + p + sx + sy, a11);
 }
 
 // DATA: also scatter the feature gradient (global atomics); otherwise only the offset gradient.
-template <bool DATA>
-__global__ __launch_bounds__(RT) void psroi_backward_kernel(const RoiArgs a)
+template <typename T, bool DATA>
+__global__ __launch_bounds__(RT) void psroi_backward_kernel(const RoiArgs<T> a)
 {
-    __shared__ float s_wstart[MAX_BINS], s_hstart[MAX_BINS];
+    __shared__ T s_wstart[MAX_BINS], s_hstart[MAX_BINS];
     __shared__ int s_gofs[MAX_BINS], s_pidx[MAX_BINS];
-    __shared__ float s_gt[2 * MAX_BINS];
+    __shared__ T s_gt[2 * MAX_BINS];
 
     const int n = blockIdx.x / a.NCLS, cls = blockIdx.x % a.NCLS;
     const int c_begin = blockIdx.y * a.chunk, c_end = min(c_begin + a.chunk, a.CEC);
     const int bins = a.PS * a.PS, parts = a.PART * a.PART;
-    const RoiBox b = roi_box(a.rois + (long)n * 5, a.scale);
+    const RoiBox<T> b = roi_box(a.rois + (long)n * 5, a.scale);
     if (b.batch < 0 || b.batch >= a.B) return;  // block-uniform: same rule as the forward kernel
 
     for (int i = threadIdx.x; i < bins; i += RT) {
-        const BinGeom g = bin_geom(a, b, n, cls, i / a.PS, i % a.PS);
+        const BinGeom<T> g = bin_geom(a, b, n, cls, i / a.PS, i % a.PS);
         s_wstart[i] = g.wstart;
         s_hstart[i] = g.hstart;
         s_gofs[i] = g.gofs;
         s_pidx[i] = g.pidx;
     }
-    for (int i = threadIdx.x; i < 2 * parts; i += RT) s_gt[i] = 0.f;
+    for (int i = threadIdx.x; i < 2 * parts; i += RT) s_gt[i] = T(0);
     __syncthreads();
 
-    float sub_w, sub_h;
+    T sub_w, sub_h;
     {
 #pragma clang fp contract(off)
-        sub_h = b.h / (float)a.PS / (float)a.SPP;
-        sub_w = b.w / (float)a.PS / (float)a.SPP;
+        sub_h = b.h / (T)a.PS / (T)a.SPP;
+        sub_w = b.w / (T)a.PS / (T)a.SPP;
     }
     const long HW = (long)a.H * a.W;
-    const float *img = a.data + (long)b.batch * a.C * HW;
-    float *gimg = a.gdata + (long)b.batch * a.C * HW;
+    const T *img = a.data + (long)b.batch * a.C * HW;
+    T *gimg = a.gdata + (long)b.batch * a.C * HW;
     const int items = (c_end - c_begin) * bins;
     for (int item = threadIdx.x; item < items; item += RT) {
         const int bin = item % bins;
         const int ctop = cls * a.CEC + c_begin + item / bins;
         const long oidx = ((long)n * a.OC + ctop) * bins + bin;
-        const float cnt = a.cnt[oidx];
-        if (cnt <= 0.f) continue;  // PK:203-206
-        const float diff_val = a.gout[oidx] / cnt;
+        const T cnt = a.cnt[oidx];
+        if (cnt <= T(0)) continue;  // PK:203-206
+        const T diff_val = a.gout[oidx] / cnt;
         const long pofs = ((long)ctop * a.GS * a.GS + s_gofs[bin]) * HW;
-        const float *plane = img + pofs;
-        float *gplane = gimg + pofs;
-        const float wstart = s_wstart[bin], hstart = s_hstart[bin];
-        float tdx = 0.f, tdy = 0.f;
+        const T *plane = img + pofs;
+        T *gplane = gimg + pofs;
+        const T wstart = s_wstart[bin], hstart = s_hstart[bin];
+        T tdx = T(0), tdy = T(0);
         // pending cell of the feature gradient
         int pend = -1, pend_sx = 0, pend_sy = 0;
-        float a00 = 0.f, a01 = 0.f, a10 = 0.f, a11 = 0.f;
+        T a00 = T(0), a01 = T(0), a10 = T(0), a11 = T(0);
         for (int ih = 0; ih < a.SPP; ++ih) {
             for (int iw = 0; iw < a.SPP; ++iw) {
-                float w, h;
+                T w, h;
                 {
 #pragma clang fp contract(off)
-                    w = wstart + (float)iw * sub_w;
-                    h = hstart + (float)ih * sub_h;
+                    w = wstart + (T)iw * sub_w;
+                    h = hstart + (T)ih * sub_h;
                 }
                 if (!keep_sample(w, h, a.W, a.H)) continue;
                 // PK:230-243
-                const int x0 = (int)floorf(w), x1 = (int)ceilf(w);
-                const int y0 = (int)floorf(h), y1 = (int)ceilf(h);
-                const float dx = w - (float)x0, dy = h - (float)y0;
+                const int x0 = (int)floor(w), x1 = (int)ceil(w);
+                const int y0 = (int)floor(h), y1 = (int)ceil(h);
+                const T dx = w - (T)x0, dy = h - (T)y0;
                 const int p = y0 * a.W + x0, sx = x1 - x0, sy = (y1 - y0) * a.W;
                 if (DATA) {
                     if (p != pend || sx != pend_sx || sy != pend_sy) {
@@ -225,33 +234,33 @@ __global__ __launch_bounds__(RT) void psroi_backward_kernel(const RoiArgs a)
                         pend = p;
                         pend_sx = sx;
                         pend_sy = sy;
-                        a00 = a01 = a10 = a11 = 0.f;
+                        a00 = a01 = a10 = a11 = T(0);
                     }
-                    a00 += (1.f - dx) * (1.f - dy) * diff_val;
-                    a01 += (1.f - dx) * dy * diff_val;
-                    a10 += dx * (1.f - dy) * diff_val;
+                    a00 += (T(1) - dx) * (T(1) - dy) * diff_val;
+                    a01 += (T(1) - dx) * dy * diff_val;
+                    a10 += dx * (T(1) - dy) * diff_val;
                     a11 += dx * dy * diff_val;
                 }
                 if (a.no_trans) continue;
                 // PK:249-256
-                const float U00 = plane[p], U01 = plane[p + sy], U10 = plane[p + sx], U11 = plane[p + sx + sy];
-                tdx += (U11 * dy + U10 * (1.f - dy) - U01 * dy - U00 * (1.f - dy)) * a.tstd * diff_val * b.w;
-                tdy += (U11 * dx + U01 * (1.f - dx) - U10 * dx - U00 * (1.f - dx)) * a.tstd * diff_val * b.h;
+                const T U00 = plane[p], U01 = plane[p + sy], U10 = plane[p + sx], U11 = plane[p + sx + sy];
+                tdx += (U11 * dy + U10 * (T(1) - dy) - U01 * dy - U00 * (T(1) - dy)) * a.tstd * diff_val * b.w;
+                tdy += (U11 * dx + U01 * (T(1) - dx) - U10 * dx - U00 * (T(1) - dx)) * a.tstd * diff_val * b.h;
             }
         }
         if (DATA && pend >= 0) flush_cell(gplane, pend, pend_sx, pend_sy, a00, a01, a10, a11);
         if (!a.no_trans) {
-            if (tdx != 0.f) atomicAdd(&s_gt[s_pidx[bin]], tdx);
-            if (tdy != 0.f) atomicAdd(&s_gt[parts + s_pidx[bin]], tdy);
+            if (tdx != T(0)) atomicAdd(&s_gt[s_pidx[bin]], tdx);
+            if (tdy != T(0)) atomicAdd(&s_gt[parts + s_pidx[bin]], tdy);
         }
     }
     if (a.no_trans) return;
     __syncthreads();
     // PK:258-259, once per cell and workgroup
-    float *gt = a.gtrans + ((long)n * a.NCLS + cls) * 2 * parts;
+    T *gt = a.gtrans + ((long)n * a.NCLS + cls) * 2 * parts;
     for (int i = threadIdx.x; i < 2 * parts; i += RT) {
-        const float v = s_gt[i];
-        if (v != 0.f) atomicAdd(gt + i, v);
+        const T v = s_gt[i];
+        if (v != T(0)) atomicAdd(gt + i, v);
     }
 }
 
@@ -260,13 +269,15 @@ __global__ __launch_bounds__(RT) void psroi_backward_kernel(const RoiArgs a)
 constexpr int ROI_CHUNK = 1024;           // RoI candidates compacted per pass
 constexpr int PLANE_LDS_MAX = 144 * 1024; // bytes of the double plane a workgroup may hold
 
-__device__ __forceinline__ void lds_add(double *cell, float v)
+template <typename T>
+__device__ __forceinline__ void lds_add(double *cell, T v)
 {
-    if (v != 0.f) __hip_atomic_fetch_add(cell, (double)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    if (v != T(0)) __hip_atomic_fetch_add(cell, (double)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 
 // grid.x = B*C score maps, grid.y = RoI slices (RoI n belongs to slice n % gridDim.y).
-__global__ __launch_bounds__(RT) void psroi_backward_plane_kernel(const RoiArgs a)
+template <typename T>
+__global__ __launch_bounds__(RT) void psroi_backward_plane_kernel(const RoiArgs<T> a)
 {
     extern __shared__ double s_plane[];               // [H*W]
     __shared__ int s_bins[MAX_BINS], s_rois[ROI_CHUNK];
@@ -283,8 +294,8 @@ __global__ __launch_bounds__(RT) void psroi_backward_plane_kernel(const RoiArgs 
     __syncthreads();
     // bins of a RoI that read this score map (PK:111-114, 130): the same for every RoI
     for (int i = threadIdx.x; i < bins; i += RT) {
-        int gw = (int)floorf((float)(i % a.PS) * (float)a.GS / (float)a.PS);
-        int gh = (int)floorf((float)(i / a.PS) * (float)a.GS / (float)a.PS);
+        int gw = (int)floor((T)(i % a.PS) * (T)a.GS / (T)a.PS);
+        int gh = (int)floor((T)(i / a.PS) * (T)a.GS / (T)a.PS);
         gw = min(max(gw, 0), a.GS - 1);
         gh = min(max(gh, 0), a.GS - 1);
         if (gh * a.GS + gw == gcell) s_bins[atomicAdd(&s_nbins, 1)] = i;
@@ -306,31 +317,31 @@ __global__ __launch_bounds__(RT) void psroi_backward_plane_kernel(const RoiArgs 
         for (int item = threadIdx.x; item < items; item += RT) {
             const int n = s_rois[item / nbins], bin = s_bins[item % nbins];
             const long oidx = ((long)n * a.OC + ctop) * bins + bin;
-            const float cnt = a.cnt[oidx];
-            if (cnt <= 0.f) continue;  // PK:203-206
-            const float diff_val = a.gout[oidx] / cnt;
-            const RoiBox box = roi_box(a.rois + (long)n * 5, a.scale);
-            const BinGeom g = bin_geom(a, box, n, cls, bin / a.PS, bin % a.PS);
-            float sub_w, sub_h;
+            const T cnt = a.cnt[oidx];
+            if (cnt <= T(0)) continue;  // PK:203-206
+            const T diff_val = a.gout[oidx] / cnt;
+            const RoiBox<T> box = roi_box(a.rois + (long)n * 5, a.scale);
+            const BinGeom<T> g = bin_geom(a, box, n, cls, bin / a.PS, bin % a.PS);
+            T sub_w, sub_h;
             {
 #pragma clang fp contract(off)
-                sub_h = box.h / (float)a.PS / (float)a.SPP;
-                sub_w = box.w / (float)a.PS / (float)a.SPP;
+                sub_h = box.h / (T)a.PS / (T)a.SPP;
+                sub_w = box.w / (T)a.PS / (T)a.SPP;
             }
             int pend = -1, pend_sx = 0, pend_sy = 0;
-            float a00 = 0.f, a01 = 0.f, a10 = 0.f, a11 = 0.f;
+            T a00 = T(0), a01 = T(0), a10 = T(0), a11 = T(0);
             for (int ih = 0; ih < a.SPP; ++ih) {
                 for (int iw = 0; iw < a.SPP; ++iw) {
-                    float w, h;
+                    T w, h;
                     {
 #pragma clang fp contract(off)
-                        w = g.wstart + (float)iw * sub_w;
-                        h = g.hstart + (float)ih * sub_h;
+                        w = g.wstart + (T)iw * sub_w;
+                        h = g.hstart + (T)ih * sub_h;
                     }
                     if (!keep_sample(w, h, a.W, a.H)) continue;
-                    const int x0 = (int)floorf(w), x1 = (int)ceilf(w);
-                    const int y0 = (int)floorf(h), y1 = (int)ceilf(h);
-                    const float dx = w - (float)x0, dy = h - (float)y0;
+                    const int x0 = (int)floor(w), x1 = (int)ceil(w);
+                    const int y0 = (int)floor(h), y1 = (int)ceil(h);
+                    const T dx = w - (T)x0, dy = h - (T)y0;
                     const int p = y0 * a.W + x0, sx = x1 - x0, sy = (y1 - y0) * a.W;
                     if (p != pend || sx != pend_sx || sy != pend_sy) {
                         if (pend >= 0) {
@@ -342,11 +353,11 @@ __global__ __launch_bounds__(RT) void psroi_backward_plane_kernel(const RoiArgs 
                         pend = p;
                         pend_sx = sx;
                         pend_sy = sy;
-                        a00 = a01 = a10 = a11 = 0.f;
+                        a00 = a01 = a10 = a11 = T(0);
                     }
-                    a00 += (1.f - dx) * (1.f - dy) * diff_val;
-                    a01 += (1.f - dx) * dy * diff_val;
-                    a10 += dx * (1.f - dy) * diff_val;
+                    a00 += (T(1) - dx) * (T(1) - dy) * diff_val;
+                    a01 += (T(1) - dx) * dy * diff_val;
+                    a10 += dx * (T(1) - dy) * diff_val;
                     a11 += dx * dy * diff_val;
                 }
             }
@@ -360,16 +371,17 @@ __global__ __launch_bounds__(RT) void psroi_backward_plane_kernel(const RoiArgs 
         __syncthreads();
     }
     // one pass over the plane: the only writer of these cells when there is one slice
-    float *gplane = a.gdata + ((long)b * a.C + c) * HW;
+    T *gplane = a.gdata + ((long)b * a.C + c) * HW;
     for (int i = threadIdx.x; i < HW; i += RT) {
-        const float v = (float)s_plane[i];
-        if (v == 0.f) continue;
+        const T v = (T)s_plane[i];
+        if (v == T(0)) continue;
         if (slices == 1) gplane[i] += v;
         else atomicAdd(gplane + i, v);
     }
 }
 
-int check_roi_geom(const ddcn_roi_geom *g, RoiArgs &a, bool backward)
+template <typename T>
+int check_roi_geom(const ddcn_roi_geom *g, RoiArgs<T> &a, bool backward)
 {
     if (!g) return fail(DDCN_ERR_BAD_ARG, "roi geom is NULL");
     if (g->B <= 0 || g->C <= 0 || g->H <= 0 || g->W <= 0)
@@ -400,17 +412,17 @@ int check_roi_geom(const ddcn_roi_geom *g, RoiArgs &a, bool backward)
     a.B = g->B; a.C = g->C; a.H = g->H; a.W = g->W; a.R = g->R;
     a.OC = g->out_channels; a.PS = g->pooled; a.GS = g->group_size; a.PART = g->part_size;
     a.SPP = g->sample_per_part; a.NCLS = ncls; a.CEC = g->out_channels / ncls; a.no_trans = g->no_trans ? 1 : 0;
-    a.scale = g->spatial_scale; a.tstd = g->trans_std;
+    a.scale = (T)g->spatial_scale; a.tstd = (T)g->trans_std;
     a.chunk = a.CEC;
     return DDCN_OK;
 }
 
-}  // namespace
 
-int launch_psroi_forward(const float *data, const float *rois, const float *trans, float *out, float *out_count,
-                         const ddcn_roi_geom *g, hipStream_t stream)
+template <typename T>
+static int psroi_forward(const T *data, const T *rois, const T *trans, T *out, T *out_count, const ddcn_roi_geom *g,
+                         hipStream_t stream)
 {
-    RoiArgs a = {};
+    RoiArgs<T> a = {};
     if (int rc = check_roi_geom(g, a, false)) return rc;
     if (a.R == 0) return DDCN_OK;
     if (!data || !rois || !out || !out_count || (!a.no_trans && !trans))
@@ -418,16 +430,16 @@ int launch_psroi_forward(const float *data, const float *rois, const float *tran
     a.data = data; a.rois = rois; a.trans = trans; a.out = out; a.out_cnt = out_count;
     const long total = (long)a.R * a.OC * a.PS * a.PS;
     const long blocks = (total + RT - 1) / RT;
-    hipLaunchKernelGGL(psroi_forward_kernel, dim3((unsigned)(blocks < (1L << 20) ? blocks : (1L << 20))), dim3(RT), 0,
+    hipLaunchKernelGGL(psroi_forward_kernel<T>, dim3((unsigned)(blocks < (1L << 20) ? blocks : (1L << 20))), dim3(RT), 0,
                        stream, a);
     return check_launch("psroi_forward");
 }
 
-int launch_psroi_backward(const float *grad_out, const float *data, const float *rois, const float *trans,
-                          const float *out_count, float *grad_data, float *grad_trans, const ddcn_roi_geom *g,
-                          hipStream_t stream)
+template <typename T>
+static int psroi_backward(const T *grad_out, const T *data, const T *rois, const T *trans, const T *out_count,
+                          T *grad_data, T *grad_trans, const ddcn_roi_geom *g, hipStream_t stream)
 {
-    RoiArgs a = {};
+    RoiArgs<T> a = {};
     if (int rc = check_roi_geom(g, a, true)) return rc;
     if (a.R == 0) return DDCN_OK;
     if (!grad_out || !data || !rois || !out_count || !grad_data || (!a.no_trans && (!trans || !grad_trans)))
@@ -454,7 +466,7 @@ int launch_psroi_backward(const float *grad_out, const float *data, const float 
     if (owner) {
         static bool attr_set = false;  // idempotent: a race only repeats the call
         if (!attr_set) {
-            if (hipFuncSetAttribute((const void *)psroi_backward_plane_kernel,
+            if (hipFuncSetAttribute((const void *)psroi_backward_plane_kernel<T>,
                                     hipFuncAttributeMaxDynamicSharedMemorySize, PLANE_LDS_MAX) != hipSuccess)
                 return fail(DDCN_ERR_LAUNCH, "psroi backward: cannot raise the LDS limit to %d bytes", PLANE_LDS_MAX);
             attr_set = true;
@@ -465,17 +477,45 @@ int launch_psroi_backward(const float *grad_out, const float *data, const float 
         if (rs > rs_max) rs = rs_max;
         if (rs < 1) rs = 1;
         if (rs > 64) rs = 64;
-        hipLaunchKernelGGL(psroi_backward_plane_kernel, dim3((unsigned)planes, (unsigned)rs), dim3(RT), plane_bytes,
+        hipLaunchKernelGGL(psroi_backward_plane_kernel<T>, dim3((unsigned)planes, (unsigned)rs), dim3(RT), plane_bytes,
                            stream, a);
         if (int rc = check_launch("psroi_backward_plane")) return rc;
         if (a.no_trans) return DDCN_OK;
-        hipLaunchKernelGGL(psroi_backward_kernel<false>, dim3((unsigned)base_wgs, (unsigned)slices), dim3(RT), 0,
+        hipLaunchKernelGGL((psroi_backward_kernel<T, false>), dim3((unsigned)base_wgs, (unsigned)slices), dim3(RT), 0,
                            stream, a);
     } else {
-        hipLaunchKernelGGL(psroi_backward_kernel<true>, dim3((unsigned)base_wgs, (unsigned)slices), dim3(RT), 0,
+        hipLaunchKernelGGL((psroi_backward_kernel<T, true>), dim3((unsigned)base_wgs, (unsigned)slices), dim3(RT), 0,
                            stream, a);
     }
     return check_launch("psroi_backward");
+}
+
+}  // namespace
+
+int launch_psroi_forward(const float *data, const float *rois, const float *trans, float *out, float *out_count,
+                         const ddcn_roi_geom *g, hipStream_t stream)
+{
+    return psroi_forward<float>(data, rois, trans, out, out_count, g, stream);
+}
+
+int launch_psroi_backward(const float *grad_out, const float *data, const float *rois, const float *trans,
+                          const float *out_count, float *grad_data, float *grad_trans, const ddcn_roi_geom *g,
+                          hipStream_t stream)
+{
+    return psroi_backward<float>(grad_out, data, rois, trans, out_count, grad_data, grad_trans, g, stream);
+}
+
+int launch_psroi_forward_f64(const double *data, const double *rois, const double *trans, double *out,
+                             double *out_count, const ddcn_roi_geom *g, hipStream_t stream)
+{
+    return psroi_forward<double>(data, rois, trans, out, out_count, g, stream);
+}
+
+int launch_psroi_backward_f64(const double *grad_out, const double *data, const double *rois, const double *trans,
+                              const double *out_count, double *grad_data, double *grad_trans, const ddcn_roi_geom *g,
+                              hipStream_t stream)
+{
+    return psroi_backward<double>(grad_out, data, rois, trans, out_count, grad_data, grad_trans, g, stream);
 }
 
 }  // namespace ddcn

@@ -74,6 +74,8 @@ PROTOTYPES = {
     "ddcn_modulated_deform_conv_forward_f16": [_P, _P, _P, _P, _P, _P, _P, _SZ, _G, _P],
     "ddcn_deform_psroi_pool_forward_f32": [_P, _P, _P, _P, _P, _RG, _P],
     "ddcn_deform_psroi_pool_backward_f32": [_P, _P, _P, _P, _P, _P, _P, _RG, _P],
+    "ddcn_deform_psroi_pool_forward_f64": [_P, _P, _P, _P, _P, _RG, _P],
+    "ddcn_deform_psroi_pool_backward_f64": [_P, _P, _P, _P, _P, _P, _P, _RG, _P],
 }
 _RESTYPES = {
     "ddcn_strerror": ctypes.c_char_p,

@@ -10,7 +10,8 @@ Deviations from the reference, all on inputs it would have read out of bounds wi
   - rois must be [R, 5] and offset [R, 2k, part_size, part_size] with k dividing out_channels; data must hold
     out_channels * group_size^2 score maps (deform_pool_cuda_kernel.cu:101-102, 130 index them unchecked);
   - a RoI whose batch index is outside the batch pools to zero;
-  - float16 / bfloat16 tensors are computed in fp32 and converted back (as in deform_conv.py here).
+  - float32 and float64 have their own kernels; float16 / bfloat16 tensors are computed in fp32 and converted back
+    (as in deform_conv.py here).
 """
 import torch
 import torch.nn as nn
@@ -19,7 +20,7 @@ from torch.autograd.function import once_differentiable
 from torch.nn.modules.utils import _pair
 
 from . import _lib
-from .deform_conv import _check_dtype_cuda, _f32
+from .deform_conv import _cast, _cdtype, _check_dtype_cuda, _entry
 
 
 def _roi_geom(data, rois, offset, spatial_scale, out_size, out_channels, no_trans, group_size, part_size,
@@ -71,20 +72,21 @@ class DeformRoIPoolingFunction(Function):
             raise RuntimeError("input tensor has to be contiguous")
 
         g = _roi_geom(data, rois, offset, *ctx.pool_args)
-        data32 = _f32(data)
-        rois32 = _f32(rois).contiguous()
-        offset32 = None if no_trans else _f32(offset).contiguous()
+        cd = _cdtype(ctx.dtype)
+        data32 = _cast(data, cd)
+        rois32 = _cast(rois, cd).contiguous()
+        offset32 = None if no_trans else _cast(offset, cd).contiguous()
         n = rois.shape[0]
-        output = torch.empty((n, out_channels, out_size, out_size), dtype=torch.float32, device=data.device)
+        output = torch.empty((n, out_channels, out_size, out_size), dtype=cd, device=data.device)
         output_count = torch.empty_like(output)
-        _lib.check(_lib.lib().ddcn_deform_psroi_pool_forward_f32(
+        _lib.check(_entry("ddcn_deform_psroi_pool_forward", cd)(
             _lib.ptr(data32), _lib.ptr(rois32), _lib.ptr(offset32), _lib.ptr(output), _lib.ptr(output_count), g,
             _lib.current_stream(data.device)))
 
         if data.requires_grad or rois.requires_grad or offset.requires_grad:  # PP:52-53
             ctx.save_for_backward(data, rois, offset)
         ctx.output_count = output_count
-        return output if ctx.dtype == torch.float32 else output.to(ctx.dtype)
+        return output if ctx.dtype == cd else output.to(ctx.dtype)
 
     @staticmethod
     @once_differentiable
@@ -94,19 +96,20 @@ class DeformRoIPoolingFunction(Function):
         data, rois, offset = ctx.saved_tensors
         no_trans = ctx.pool_args[3]
         g = _roi_geom(data, rois, offset, *ctx.pool_args)
-        data32 = _f32(data)
-        rois32 = _f32(rois).contiguous()
-        offset32 = None if no_trans else _f32(offset).contiguous()
-        grad_out32 = _f32(grad_output).contiguous()  # deform_pool_cuda.cpp:63 demanded contiguity; made so here
+        cd = _cdtype(ctx.dtype)
+        data32 = _cast(data, cd)
+        rois32 = _cast(rois, cd).contiguous()
+        offset32 = None if no_trans else _cast(offset, cd).contiguous()
+        grad_out32 = _cast(grad_output, cd).contiguous()  # deform_pool_cuda.cpp:63 demanded contiguity; made so here
 
         # PP:66-68: both gradients start from zero, the kernel accumulates
-        grad_input = torch.zeros(data.shape, dtype=torch.float32, device=data.device)
-        grad_offset = torch.zeros(offset.shape, dtype=torch.float32, device=data.device)
-        _lib.check(_lib.lib().ddcn_deform_psroi_pool_backward_f32(
+        grad_input = torch.zeros(data.shape, dtype=cd, device=data.device)
+        grad_offset = torch.zeros(offset.shape, dtype=cd, device=data.device)
+        _lib.check(_entry("ddcn_deform_psroi_pool_backward", cd)(
             _lib.ptr(grad_out32), _lib.ptr(data32), _lib.ptr(rois32), _lib.ptr(offset32),
             _lib.ptr(ctx.output_count), _lib.ptr(grad_input), None if no_trans else _lib.ptr(grad_offset), g,
             _lib.current_stream(data.device)))
-        if ctx.dtype != torch.float32:
+        if ctx.dtype != cd:
             grad_input, grad_offset = grad_input.to(ctx.dtype), grad_offset.to(ctx.dtype)
         # no gradient for rois (PP:67) nor for the eight scalars
         return (grad_input, None, grad_offset) + (None,) * 8

@@ -181,6 +181,34 @@ def test_packs_start_from_rigid_pooling_and_train():
     assert float(mm.mask_fc[2].weight.grad.abs().sum()) > 0
 
 
+@pytest.mark.parametrize("case", [c for c in PSROI_CASES if c["R"]], ids=lambda c: c["name"])
+def test_fp64_kernels_match_golden(case):
+    g = load_golden("psroi_" + case["name"])
+    _, _, _, _, kw = make_psroi_inputs(case, np.float32)
+    d = torch.from_numpy(g["data"]).to(DEV).requires_grad_(True)
+    o = torch.from_numpy(g["offset"] if "offset" in g else np.zeros(0)).to(DEV).requires_grad_(not kw["no_trans"])
+    out = pkg.deform_roi_pooling(d, torch.from_numpy(g["rois"]).to(DEV), o, *_args(kw))
+    assert out.dtype == torch.float64
+    out.backward(torch.from_numpy(g["gout"]).to(DEV))
+    assert cases.relerr(out.detach().cpu().numpy(), g["out"]) <= 1e-12
+    assert cases.relerr(d.grad.cpu().numpy(), g["gdata"]) <= 1e-11
+    if not kw["no_trans"]:
+        assert cases.relerr(o.grad.cpu().numpy(), g["goff"]) <= 1e-11
+
+
+def test_fp64_gradcheck_of_the_pooling_operator():
+    """torch.autograd.gradcheck on the HIP operator in double, with the settings of the reference's convolution
+    self-test (detseg/ops/dcn/test.py:208-267) -- the reference has no such test for the pooling."""
+    case = dict(name="gc", B=2, out_channels=4, group_size=2, H=9, W=11, R=3, out_size=3, part_size=3,
+                sample_per_part=2, trans_std=0.2, spatial_scale=0.3, classes=2, no_trans=False, seed=9)
+    data, rois, offset, _, kw = make_psroi_inputs(case, np.float64)
+    d = torch.from_numpy(data * 0.1).to(DEV).requires_grad_(True)
+    o = torch.from_numpy(offset).to(DEV).requires_grad_(True)
+    r = torch.from_numpy(rois).to(DEV)
+    fn = lambda a, b: pkg.deform_roi_pooling(a, r, b, *_args(kw))
+    assert torch.autograd.gradcheck(fn, (d, o), eps=1e-6, atol=1e-6, rtol=1e-4, raise_exception=True, nondet_tol=1e-9)
+
+
 def test_half_tensors_are_computed_in_fp32():
     case = MEDIUM[0]
     data, rois, offset, gout, kw = make_psroi_inputs(case, np.float32)
