@@ -171,6 +171,8 @@ def model_workload(args, world, rank, dev):
                               norm_eval=False, deep_base=cfg["deep_base"])
     model = callers.DANet(backbone, callers.DANetHead(2048, cfg["classes"]), callers.PointNet(),
                           dcn_offset_init=args.offset_init).to(dev).train()
+    if world > 1 and args.syncbn:
+        model = torch.nn.SyncBatchNorm.convert_sync_batchnorm(model)
     opt = callers.build_optimizer(model)
     # N > 1: gradient buckets are all-reduced (RCCL) from inside backward; --sync-allreduce reduces after it
     reducer = callers.OverlappedGradReducer(model) if (world > 1 and not args.sync_allreduce) else None
@@ -211,6 +213,7 @@ def model_workload(args, world, rank, dev):
                        "images_per_gpu": n, "parallelism": "dp%d" % world,
                        "params_M": round(sum(p.numel() for p in model.parameters()) / 1e6, 2),
                        "dcn_offset_init": args.offset_init,
+                       "norm": "SyncBN" if (world > 1 and args.syncbn) else "BN",
                        "allreduce": "none" if world == 1 else ("after backward" if reducer is None else
                                                                "32 MiB buckets, overlapped with backward")},
             "final_loss": round(float(loss), 4),
@@ -297,6 +300,9 @@ def main():
     ap.add_argument("--offset-init", choices=("zero", "kaiming"), default="zero",
                     help="model workloads: DDCN offset convolutions start at zero (the reference's intent) or Kaiming "
                          "(what its init_weights really does: ~6 px offsets)")
+    ap.add_argument("--syncbn", action="store_true",
+                    help="model workloads, N > 1: SyncBatchNorm as in configs/sunrgbd/danet_r101_depthdeform.py "
+                         "(per-layer statistics exchanged over RCCL); default is plain BN per rank")
     ap.add_argument("--sync-allreduce", action="store_true",
                     help="model workloads, N > 1: all-reduce after backward (the reference's order) instead of under it")
     ap.add_argument("--no-graph", action="store_true", help="cfg5: launch eagerly instead of replaying a HIP graph")
