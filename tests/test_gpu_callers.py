@@ -88,3 +88,33 @@ def test_r101_deep_base_forward_backward_small():
     loss.backward()
     assert torch.isfinite(loss)
     assert m.backbone.layer3[22].conv2.weight.grad is not None
+
+
+def test_overlapped_reducer_on_rccl_single_rank():
+    """The N > 1 gradient path on the real backend ("nccl" = RCCL), world size 1: asynchronous bucket all-reduces
+    issued from inside backward on RCCL's stream, then the SGD step; results must equal the plain step."""
+    import os
+    import socket
+    import torch.distributed as dist
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device(DEV))
+    try:
+        b = _batch(2, 64, 64, 5, seed=3)
+        ref = _model(classes=5).eval()
+        opt = callers.build_optimizer(ref, lr=0.001)
+        l0 = float(callers.train_step(ref, opt, b, it=0, max_iters=4))
+        m = _model(classes=5).eval()          # same seed -> same initial weights
+        reducer = callers.OverlappedGradReducer(m, bucket_size_mb=4)
+        assert len(reducer.buckets) > 4
+        opt2 = callers.build_optimizer(m, lr=0.001)
+        l1 = float(callers.train_step(m, opt2, b, it=0, max_iters=4, reducer=reducer))
+        torch.cuda.synchronize()
+        assert abs(l0 - l1) <= 1e-5 * abs(l0)
+        for p, q in zip(ref.parameters(), m.parameters()):
+            assert torch.allclose(p, q, rtol=1e-4, atol=1e-6)
+        reducer.remove()
+    finally:
+        dist.destroy_process_group()
