@@ -380,6 +380,101 @@ __global__ __launch_bounds__(RT) void psroi_backward_plane_kernel(const RoiArgs<
     }
 }
 
+// ---- forward, plane-owner formulation: the score map is read once into LDS and every sample is taken from there
+// (four ds_read_b32 instead of four scattered global loads).  Same arithmetic and summation order as
+// psroi_forward_kernel, so both give the same bits.  grid.x = B*C score maps, grid.y = RoI slices.
+template <typename T>
+__global__ __launch_bounds__(RT) void psroi_forward_plane_kernel(const RoiArgs<T> a)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char s_fraw[];
+    T *s_map = reinterpret_cast<T *>(s_fraw);          // [H*W]
+    __shared__ int s_bins[MAX_BINS], s_rois[ROI_CHUNK];
+    __shared__ int s_nbins, s_nrois;
+
+    const int b = blockIdx.x / a.C, c = blockIdx.x % a.C;
+    const int gs2 = a.GS * a.GS;
+    const int ctop = c / gs2, gcell = c % gs2, cls = ctop / a.CEC;
+    const int bins = a.PS * a.PS, HW = a.H * a.W;
+    const int slices = gridDim.y, slice = blockIdx.y;
+
+    const T *src = a.data + ((long)b * a.C + c) * HW;
+    for (int i = threadIdx.x; i < HW; i += RT) s_map[i] = src[i];
+    if (threadIdx.x == 0) s_nbins = 0;
+    __syncthreads();
+    for (int i = threadIdx.x; i < bins; i += RT) {     // bins that read this score map (PK:111-114, 130)
+        int gw = (int)floor((T)(i % a.PS) * (T)a.GS / (T)a.PS);
+        int gh = (int)floor((T)(i / a.PS) * (T)a.GS / (T)a.PS);
+        gw = min(max(gw, 0), a.GS - 1);
+        gh = min(max(gh, 0), a.GS - 1);
+        if (gh * a.GS + gw == gcell) s_bins[atomicAdd(&s_nbins, 1)] = i;
+    }
+    __syncthreads();
+    const int nbins = s_nbins;
+    if (nbins == 0) return;   // block-uniform: no bin of any RoI reads this map
+
+    const int per_pass = ROI_CHUNK * slices;
+    for (int base = 0; base < a.R; base += per_pass) {
+        if (threadIdx.x == 0) s_nrois = 0;
+        __syncthreads();
+        for (int k = threadIdx.x; k < ROI_CHUNK; k += RT) {
+            const int n = base + k * slices + slice;
+            if (n < a.R && (int)a.rois[(long)n * 5] == b) s_rois[atomicAdd(&s_nrois, 1)] = n;
+        }
+        __syncthreads();
+        const int items = s_nrois * nbins;
+        for (int item = threadIdx.x; item < items; item += RT) {
+            const int n = s_rois[item / nbins], bin = s_bins[item % nbins];
+            const RoiBox<T> box = roi_box(a.rois + (long)n * 5, a.scale);
+            const BinGeom<T> g = bin_geom(a, box, n, cls, bin / a.PS, bin % a.PS);
+            T sub_w, sub_h;
+            {
+#pragma clang fp contract(off)
+                sub_h = box.h / (T)a.PS / (T)a.SPP;
+                sub_w = box.w / (T)a.PS / (T)a.SPP;
+            }
+            T sum = T(0);
+            int count = 0;
+            for (int ih = 0; ih < a.SPP; ++ih) {
+                for (int iw = 0; iw < a.SPP; ++iw) {
+                    T w, h;
+                    {
+#pragma clang fp contract(off)
+                        w = g.wstart + (T)iw * sub_w;
+                        h = g.hstart + (T)ih * sub_h;
+                    }
+                    if (!keep_sample(w, h, a.W, a.H)) continue;
+                    const int x1 = (int)floor(w), x2 = (int)ceil(w);
+                    const int y1 = (int)floor(h), y2 = (int)ceil(h);
+                    const T dx = w - (T)x1, dy = h - (T)y1;
+                    const T v11 = s_map[y1 * a.W + x1], v12 = s_map[y2 * a.W + x1];
+                    const T v21 = s_map[y1 * a.W + x2], v22 = s_map[y2 * a.W + x2];
+                    sum += (T(1) - dx) * (T(1) - dy) * v11 + (T(1) - dx) * dy * v12 + dx * (T(1) - dy) * v21 +
+                           dx * dy * v22;
+                    ++count;
+                }
+            }
+            const long oidx = ((long)n * a.OC + ctop) * bins + bin;
+            a.out[oidx] = count == 0 ? T(0) : sum / (T)count;
+            a.out_cnt[oidx] = (T)count;
+        }
+        __syncthreads();
+    }
+}
+
+// RoIs whose batch index names no image of the batch are visited by no plane owner: their outputs are zero.
+template <typename T>
+__global__ __launch_bounds__(RT) void psroi_forward_orphans_kernel(const RoiArgs<T> a)
+{
+    const int n = blockIdx.x;
+    const int batch = (int)a.rois[(long)n * 5];
+    if (batch >= 0 && batch < a.B) return;
+    const long per = (long)a.OC * a.PS * a.PS;
+    for (long i = threadIdx.x; i < per; i += RT) {
+        a.out[n * per + i] = T(0);
+        a.out_cnt[n * per + i] = T(0);
+    }
+}
+
 template <typename T>
 int check_roi_geom(const ddcn_roi_geom *g, RoiArgs<T> &a, bool backward)
 {
@@ -428,6 +523,29 @@ static int psroi_forward(const T *data, const T *rois, const T *trans, T *out, T
     if (!data || !rois || !out || !out_count || (!a.no_trans && !trans))
         return fail(DDCN_ERR_BAD_ARG, "psroi forward: NULL tensor pointer");
     a.data = data; a.rois = rois; a.trans = trans; a.out = out; a.out_cnt = out_count;
+    // plane owners when a score map fits in LDS and the launch gets enough of them (DDCN_PSROI_PLANE_FWD=0: never)
+    const size_t map_bytes = (size_t)a.H * a.W * sizeof(T);
+    const long planes = (long)a.B * a.C;
+    static const int env_plane = getenv("DDCN_PSROI_PLANE_FWD") ? atoi(getenv("DDCN_PSROI_PLANE_FWD")) : 1;
+    if (env_plane && map_bytes <= (size_t)PLANE_LDS_MAX && a.PS * a.PS <= MAX_BINS && planes < (1L << 31) &&
+        planes * ((a.R + 31) / 32) >= 256 && a.R <= 65535 * 32) {
+        static bool attr_set = false;
+        if (!attr_set) {
+            if (hipFuncSetAttribute((const void *)psroi_forward_plane_kernel<T>,
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, PLANE_LDS_MAX) != hipSuccess)
+                return fail(DDCN_ERR_LAUNCH, "psroi forward: cannot raise the LDS limit to %d bytes", PLANE_LDS_MAX);
+            attr_set = true;
+        }
+        long rs = (2048 + planes - 1) / planes;
+        const long rs_max = (a.R + 31) / 32;
+        if (rs > rs_max) rs = rs_max;
+        if (rs < 1) rs = 1;
+        if (rs > 64) rs = 64;
+        hipLaunchKernelGGL(psroi_forward_orphans_kernel<T>, dim3((unsigned)a.R), dim3(RT), 0, stream, a);
+        hipLaunchKernelGGL(psroi_forward_plane_kernel<T>, dim3((unsigned)planes, (unsigned)rs), dim3(RT), map_bytes,
+                           stream, a);
+        return check_launch("psroi_forward_plane");
+    }
     const long total = (long)a.R * a.OC * a.PS * a.PS;
     const long blocks = (total + RT - 1) / RT;
     hipLaunchKernelGGL(psroi_forward_kernel<T>, dim3((unsigned)(blocks < (1L << 20) ? blocks : (1L << 20))), dim3(RT), 0,

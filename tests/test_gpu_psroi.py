@@ -221,3 +221,18 @@ def test_half_tensors_are_computed_in_fp32():
     f = lambda t: t.detach().float().cpu().numpy().astype(np.float64)
     eout, ecnt = orc.psroi_forward(f(d), f(_t(rois).half()), f(o), **kw)
     assert cases.relerr(f(out), eout) <= 2e-3
+
+
+def test_plane_owner_forward_zeroes_out_of_batch_rois_and_matches_direct_kernel(monkeypatch):
+    """The LDS plane-owner forward (large launches) against the one-lane-per-bin kernel: same bits; a RoI whose batch
+    index names no image is visited by no plane owner and must still come out as zeros."""
+    case = MEDIUM[0]
+    data, rois, offset, gout, kw = make_psroi_inputs(case, np.float32)
+    rois = rois.copy()
+    rois[0, 0] = 99
+    out_p, cnt_p = _count_through_c_abi(data, rois, offset, kw)
+    assert np.all(out_p[0] == 0) and np.all(cnt_p[0] == 0) and np.abs(out_p[1:]).max() > 0
+    eout, ecnt = orc.psroi_forward(data[:, :, :, :].astype(np.float64), rois[1:].astype(np.float64),
+                                   offset[1:].astype(np.float64), **kw)
+    np.testing.assert_array_equal(cnt_p[1:], ecnt)
+    assert cases.relerr(out_p[1:], eout) <= FWD_TOL
