@@ -276,10 +276,13 @@ __device__ __forceinline__ void lds_add(double *cell, T v)
 }
 
 // grid.x = B*C score maps, grid.y = RoI slices (RoI n belongs to slice n % gridDim.y).
-template <typename T>
+// TRANS: the workgroup also keeps its score map in LDS and adds this channel's share of the offset gradient, two global
+// atomics per (RoI, bin) instead of a second kernel that gathers every sample from global memory again; the item
+// order is rotated by the channel so that the channels of a class do not hit one offset cell at the same moment.
+template <typename T, bool TRANS>
 __global__ __launch_bounds__(RT) void psroi_backward_plane_kernel(const RoiArgs<T> a)
 {
-    extern __shared__ double s_plane[];               // [H*W]
+    extern __shared__ double s_plane[];               // [H*W] gradient plane, then (TRANS) [H*W] score map as T
     __shared__ int s_bins[MAX_BINS], s_rois[ROI_CHUNK];
     __shared__ int s_nbins, s_nrois;
 
@@ -289,7 +292,13 @@ __global__ __launch_bounds__(RT) void psroi_backward_plane_kernel(const RoiArgs<
     const int bins = a.PS * a.PS, HW = a.H * a.W;
     const int slices = gridDim.y, slice = blockIdx.y;
 
+    T *s_map = reinterpret_cast<T *>(s_plane + HW);
     for (int i = threadIdx.x; i < HW; i += RT) s_plane[i] = 0.0;
+    if (TRANS) {
+        const T *src = a.data + ((long)b * a.C + c) * HW;
+        for (int i = threadIdx.x; i < HW; i += RT) s_map[i] = src[i];
+    }
+    const int parts = a.PART * a.PART;
     if (threadIdx.x == 0) s_nbins = 0;
     __syncthreads();
     // bins of a RoI that read this score map (PK:111-114, 130): the same for every RoI
@@ -314,7 +323,10 @@ __global__ __launch_bounds__(RT) void psroi_backward_plane_kernel(const RoiArgs<
         }
         __syncthreads();
         const int items = s_nrois * nbins;
-        for (int item = threadIdx.x; item < items; item += RT) {
+        const int rot = items > 0 ? (int)(((long)c * 61 * RT) % items) : 0;
+        for (int it = threadIdx.x; it < items; it += RT) {
+            int item = it + rot;
+            if (item >= items) item -= items;
             const int n = s_rois[item / nbins], bin = s_bins[item % nbins];
             const long oidx = ((long)n * a.OC + ctop) * bins + bin;
             const T cnt = a.cnt[oidx];
@@ -330,6 +342,7 @@ __global__ __launch_bounds__(RT) void psroi_backward_plane_kernel(const RoiArgs<
             }
             int pend = -1, pend_sx = 0, pend_sy = 0;
             T a00 = T(0), a01 = T(0), a10 = T(0), a11 = T(0);
+            T tdx = T(0), tdy = T(0);
             for (int ih = 0; ih < a.SPP; ++ih) {
                 for (int iw = 0; iw < a.SPP; ++iw) {
                     T w, h;
@@ -359,6 +372,11 @@ __global__ __launch_bounds__(RT) void psroi_backward_plane_kernel(const RoiArgs<
                     a01 += (T(1) - dx) * dy * diff_val;
                     a10 += dx * (T(1) - dy) * diff_val;
                     a11 += dx * dy * diff_val;
+                    if (TRANS) {   // PK:249-256
+                        const T U00 = s_map[p], U01 = s_map[p + sy], U10 = s_map[p + sx], U11 = s_map[p + sx + sy];
+                        tdx += (U11 * dy + U10 * (T(1) - dy) - U01 * dy - U00 * (T(1) - dy)) * a.tstd * diff_val * box.w;
+                        tdy += (U11 * dx + U01 * (T(1) - dx) - U10 * dx - U00 * (T(1) - dx)) * a.tstd * diff_val * box.h;
+                    }
                 }
             }
             if (pend >= 0) {
@@ -366,6 +384,11 @@ __global__ __launch_bounds__(RT) void psroi_backward_plane_kernel(const RoiArgs<
                 lds_add(s_plane + pend + pend_sy, a01);
                 lds_add(s_plane + pend + pend_sx, a10);
                 lds_add(s_plane + pend + pend_sx + pend_sy, a11);
+            }
+            if (TRANS) {       // PK:258-259, once per (RoI, bin, channel)
+                T *gt = a.gtrans + ((long)n * a.NCLS + cls) * 2 * parts + g.pidx;
+                if (tdx != T(0)) atomicAdd(gt, tdx);
+                if (tdy != T(0)) atomicAdd(gt + parts, tdy);
             }
         }
         __syncthreads();
@@ -584,7 +607,9 @@ static int psroi_backward(const T *grad_out, const T *data, const T *rois, const
     if (owner) {
         static bool attr_set = false;  // idempotent: a race only repeats the call
         if (!attr_set) {
-            if (hipFuncSetAttribute((const void *)psroi_backward_plane_kernel<T>,
+            if (hipFuncSetAttribute((const void *)psroi_backward_plane_kernel<T, false>,
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, PLANE_LDS_MAX) != hipSuccess ||
+                hipFuncSetAttribute((const void *)psroi_backward_plane_kernel<T, true>,
                                     hipFuncAttributeMaxDynamicSharedMemorySize, PLANE_LDS_MAX) != hipSuccess)
                 return fail(DDCN_ERR_LAUNCH, "psroi backward: cannot raise the LDS limit to %d bytes", PLANE_LDS_MAX);
             attr_set = true;
@@ -595,8 +620,17 @@ static int psroi_backward(const T *grad_out, const T *data, const T *rois, const
         if (rs > rs_max) rs = rs_max;
         if (rs < 1) rs = 1;
         if (rs > 64) rs = 64;
-        hipLaunchKernelGGL(psroi_backward_plane_kernel<T>, dim3((unsigned)planes, (unsigned)rs), dim3(RT), plane_bytes,
-                           stream, a);
+        // offset gradient inside the plane owners when the score map fits next to the gradient plane
+        // (DDCN_PSROI_FUSED_TRANS=0: separate kernel)
+        static const int env_fused = getenv("DDCN_PSROI_FUSED_TRANS") ? atoi(getenv("DDCN_PSROI_FUSED_TRANS")) : 1;
+        const size_t both = plane_bytes + (size_t)a.H * a.W * sizeof(T);
+        if (!a.no_trans && env_fused && both <= (size_t)PLANE_LDS_MAX) {
+            hipLaunchKernelGGL((psroi_backward_plane_kernel<T, true>), dim3((unsigned)planes, (unsigned)rs), dim3(RT),
+                               both, stream, a);
+            return check_launch("psroi_backward_plane");
+        }
+        hipLaunchKernelGGL((psroi_backward_plane_kernel<T, false>), dim3((unsigned)planes, (unsigned)rs), dim3(RT),
+                           plane_bytes, stream, a);
         if (int rc = check_launch("psroi_backward_plane")) return rc;
         if (a.no_trans) return DDCN_OK;
         hipLaunchKernelGGL((psroi_backward_kernel<T, false>), dim3((unsigned)base_wgs, (unsigned)slices), dim3(RT), 0,
