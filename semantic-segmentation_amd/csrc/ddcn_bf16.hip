@@ -173,6 +173,30 @@ __global__ __launch_bounds__(256) void repack_w_kernel(const bf16_t *w, bf16_t *
     wp[i] = w[row * K + (oct * 8 + e) * 9 + tap];
 }
 
+// The same permutation into the layout of the LDS-DMA GEMMs: W''[group][K/32][M][32], zero-padded to whole 32-k
+// steps.  The A tile of one K step is then one contiguous run of 64 bytes per row (whole 128-byte lines per request;
+// row-major rows of K put every 64-byte piece in a line of its own, and the other half of that line has left the L1
+// by the time the next K step asks for it).
+__global__ __launch_bounds__(256) void repack_w_blocked_kernel(const bf16_t *w, bf16_t *wp, long total, int K, int M)
+{
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int KT = (K + 31) / 32;
+    const int k32 = (int)(i & 31);
+    const long rest = i >> 5;
+    const int row = (int)(rest % M);
+    const long gk = rest / M;
+    const int kt = (int)(gk % KT);
+    const long grp = gk / KT;
+    const int kk = kt * 32 + k32;
+    bf16_t v = 0;
+    if (kk < K) {
+        const int e = kk & 7, tap = (kk >> 3) % 9, oct = (kk >> 3) / 9;
+        v = w[(grp * M + row) * K + (oct * 8 + e) * 9 + tap];
+    }
+    wp[i] = v;
+}
+
 // ---------------------------------------------------------------- LDS-tiled im2col
 constexpr int TH = 8, TW = 32;
 
@@ -473,40 +497,48 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t uniform_rsrc(const void *p, un
 // 4 -> 256-row tile (128x64 per wave: 6 fragment reads per 8 MFMAs, the LDS pipe stops being the co-bottleneck).
 constexpr unsigned wait_vm_lgkm0(int vm) { return (unsigned)((vm & 0xF) | ((vm >> 4) << 14) | 0x0070); }
 
-template <typename T, int NS, int MI>
-__global__ __launch_bounds__(GT, MI == 4 ? 2 : (NS == 2 ? 4 : (NS == 3 ? 3 : 2))) void gemm16_dma_kernel(const Bf16Args a)
+// NWN = wave columns: 2 -> 4 waves, 128 pixels per tile; 4 -> 8 waves, 256 pixels (with MI = 4 a 256x256 tile: 128
+// flop per operand byte fetched through L1/L2 instead of 85, one workgroup of two waves per SIMD on a CU).
+template <typename T, int NS, int MI, int NWN = 2>
+__global__ __launch_bounds__(128 * NWN, NWN == 4 ? 1 : (MI == 4 ? 2 : (NS == 2 ? 4 : (NS == 3 ? 3 : 2))))
+void gemm16_dma_kernel(const Bf16Args a)
 {
+    constexpr int NT = 128 * NWN;                 // threads; waves = 2 (rows) x NWN (columns)
+    constexpr int NWAVES = NT / 64;
+    constexpr int BNW = 64 * NWN;                 // pixels of the workgroup tile
     constexpr int BMK = 2 * MI * 32;              // rows of the workgroup tile
-    constexpr int RA = BMK * 4 / GT;              // A requests per thread and stage (B: 2)
-    constexpr int STAGE = BMK * 4 + 512;          // 16-byte chunks per stage
-    extern __shared__ u32x4 ring[];   // NS stages of [A: BMK rows x 4 chunks][B: 4 octets x 128 pixels]
+    constexpr int RA = BMK * 4 / NT;              // A requests per thread and stage
+    constexpr int RB = BNW * 4 / NT;              // B requests per thread and stage (= 2)
+    constexpr int STAGE = BMK * 4 + BNW * 4;      // 16-byte chunks per stage
+    extern __shared__ u32x4 ring[];   // NS stages of [A: BMK rows x 4 chunks][B: 4 octets x BNW pixels]
     const int t = threadIdx.x, lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);   // uniform: the DMA's LDS base goes through M0
-    const int wm = wave >> 1, wn = wave & 1;
-    const int tiles_m = (a.Cog + BMK - 1) / BMK;
-    const int L = xcd_logical(blockIdx.x, tiles_m * a.tiles_n);
-    const int m0 = (L % tiles_m) * BMK, n0 = (L / tiles_m) * BN;
+    const int wm = wave / NWN, wn = wave % NWN;
+    const int tiles_m = (a.Cog + BMK - 1) / BMK, tiles_n = (a.P + BNW - 1) / BNW;
+    const int L = xcd_logical(blockIdx.x, tiles_m * tiles_n);
+    const int m0 = (L % tiles_m) * BMK, n0 = (L / tiles_m) * BNW;
     const int img = blockIdx.y / a.groups, grp = blockIdx.y % a.groups;
     const int M = a.Cog, K = a.Kg, KOg = K / 8;
 
-    const __amdgpu_buffer_rsrc_t rA = uniform_rsrc(a.weight + (long)grp * M * K, (unsigned)((long)M * K * 2));
+    // weights as repack_w_blocked_kernel leaves them: [group][K/32][M][32], zero-padded in k
+    const int ntiles = (K + DK - 1) / DK;
+    const __amdgpu_buffer_rsrc_t rA = uniform_rsrc(a.weight + (long)grp * ntiles * M * DK,
+                                                   (unsigned)((long)ntiles * M * DK * 2));
     const __amdgpu_buffer_rsrc_t rB = uniform_rsrc((const u32x4 *)a.col + ((long)img * a.KO + (long)grp * KOg) * a.P,
                                                    (unsigned)((long)KOg * a.P * 16));
 
-    // this thread's RA chunks of A and two of B per stage; request r of wave w fills ring chunks (r*4+w)*64 + lane
-    unsigned offA[RA], offB[2];
-    int kcA[RA];
+    // this thread's RA chunks of A and RB of B per stage; request r of wave w fills ring chunks (r*NWAVES+w)*64 + lane
+    unsigned offA[RA], offB[RB];
 #pragma unroll
     for (int r = 0; r < RA; ++r) {
-        const int q = (r * 4 + wave) * 64 + lane;
+        const int q = (r * NWAVES + wave) * 64 + lane;
         const int row = q >> 2, c = (q & 3) ^ ((row >> 2) & 3);
-        kcA[r] = c * 8;
-        offA[r] = (m0 + row < M) ? (unsigned)(((m0 + row) * K + c * 8) * 2) : DMA_OOB;
+        offA[r] = (m0 + row < M) ? (unsigned)(((m0 + row) * DK + c * 8) * 2) : DMA_OOB;
     }
 #pragma unroll
-    for (int r = 0; r < 2; ++r) {
-        const int q = (r * 4 + wave) * 64 + lane;
-        const int oct = q >> 7, nn = n0 + (q & 127);
+    for (int r = 0; r < RB; ++r) {
+        const int q = (r * NWAVES + wave) * 64 + lane;
+        const int oct = q / BNW, nn = n0 + (q % BNW);
         offB[r] = (nn < a.P) ? (unsigned)((oct * a.P + nn) * 16) : DMA_OOB;
     }
     auto request = [&](int kt) {
@@ -514,13 +546,14 @@ __global__ __launch_bounds__(GT, MI == 4 ? 2 : (NS == 2 ? 4 : (NS == 3 ? 3 : 2))
         char *base = (char *)(ring + st * STAGE) + wave * 1024;
 #pragma unroll
         for (int r = 0; r < RA; ++r) {
-            const unsigned va = (offA[r] != DMA_OOB && k0 + kcA[r] < K) ? offA[r] + (unsigned)(k0 * 2) : DMA_OOB;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, (lds_void *)(base + r * 4096), 16, va, 0, 0, 0);
+            const unsigned va = offA[r] != DMA_OOB ? offA[r] + (unsigned)(kt * M * DK * 2) : DMA_OOB;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, (lds_void *)(base + r * (NWAVES * 1024)), 16, va, 0, 0, 0);
         }
 #pragma unroll
-        for (int r = 0; r < 2; ++r) {
+        for (int r = 0; r < RB; ++r) {
             const unsigned vb = offB[r] != DMA_OOB ? offB[r] + (unsigned)((k0 / 8) * a.P * 16) : DMA_OOB;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rB, (lds_void *)(base + BMK * 64 + r * 4096), 16, vb, 0, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rB, (lds_void *)(base + BMK * 64 + r * (NWAVES * 1024)), 16, vb, 0,
+                                                     0, 0);
         }
     };
 
@@ -533,17 +566,16 @@ __global__ __launch_bounds__(GT, MI == 4 ? 2 : (NS == 2 ? 4 : (NS == 3 ? 3 : 2))
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
     const int r32 = lane & 31, hi = lane >> 5;
-    const int ntiles = (K + DK - 1) / DK;
 #pragma unroll
     for (int kt = 0; kt < NS - 1; ++kt)
         if (kt < ntiles) request(kt);
     for (int kt = 0; kt < ntiles; ++kt) {
-        // younger tiles still allowed in flight: RA + 2 requests each
+        // younger tiles still allowed in flight: RA + RB requests each
         const int rem = min(NS - 2, ntiles - 1 - kt);
         // one s_waitcnt: this wave's LDS reads of tile kt-1 are done (lgkmcnt 0) and its requests of tile kt have
         // landed (vmcnt counts the requests that may stay in flight).  A plain __syncthreads() would drain vmcnt to 0.
-        if (rem >= 2) __builtin_amdgcn_s_waitcnt(wait_vm_lgkm0(2 * (RA + 2)));
-        else if (rem == 1) __builtin_amdgcn_s_waitcnt(wait_vm_lgkm0(RA + 2));
+        if (rem >= 2) __builtin_amdgcn_s_waitcnt(wait_vm_lgkm0(2 * (RA + RB)));
+        else if (rem == 1) __builtin_amdgcn_s_waitcnt(wait_vm_lgkm0(RA + RB));
         else __builtin_amdgcn_s_waitcnt(wait_vm_lgkm0(0));
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
@@ -559,7 +591,7 @@ __global__ __launch_bounds__(GT, MI == 4 ? 2 : (NS == 2 ? 4 : (NS == 3 ? 3 : 2))
                 fa[i] = As[row * 4 + ((s * 2 + hi) ^ ((row >> 2) & 3))];
             }
 #pragma unroll
-            for (int j = 0; j < 2; ++j) fb[j] = Bs[(s * 2 + hi) * BN + wn * 64 + j * 32 + r32];
+            for (int j = 0; j < 2; ++j) fb[j] = Bs[(s * 2 + hi) * BNW + wn * 64 + j * 32 + r32];
 #pragma unroll
             for (int i = 0; i < MI; ++i)
 #pragma unroll
@@ -596,7 +628,8 @@ static size_t col_bytes(const ddcn_geom &g)
 // bf16 columns of all N images, then the repacked weights
 size_t bf16_workspace_bytes(const ddcn_geom &g)
 {
-    return col_bytes(g) + (size_t)g.Co * (g.C / g.groups) * 9 * 2;
+    const size_t kpad = ((size_t)(g.C / g.groups) * 9 + 31) / 32 * 32;   // whole 32-k steps (blocked layout)
+    return col_bytes(g) + (size_t)g.Co * kpad * 2;
 }
 
 // 0 when the native bf16 path covers the geometry, else DDCN_ERR_UNSUPPORTED with the reason
@@ -677,11 +710,24 @@ static int forward_16(const void *x, const void *weight, const void *bias, const
     a.tiles_m = (a.Cog + BM - 1) / BM;
     a.tiles_n = (a.P + BN - 1) / BN;
 
+    // GEMM variant: LDS-DMA ring (default 4 stages; DDCN_BF16_GEMM_STAGES=0 selects the register-staged kernel).  The
+    // DMA kernels address W and one (image, group) columns slab with 31-bit byte offsets.
+    const char *es = getenv("DDCN_BF16_GEMM_STAGES");
+    const int stages = es ? atoi(es) : 4;
+    const long kpad = (long)(a.Kg + 31) / 32 * 32;
+    const bool dma = stages >= 2 && (long)a.Cog * kpad * 2 < (1L << 31) && (long)(a.Kg / 8) * a.P * 16 < (1L << 31);
+
     // weights into the path's k order (a permutation of 16-bit words: the same kernel for both formats)
     bf16_t *wp = (bf16_t *)((char *)ws + col_bytes(g));
-    const long wtotal = (long)g.Co * a.Kg;
-    hipLaunchKernelGGL(repack_w_kernel, dim3((unsigned)((wtotal + 255) / 256)), dim3(256), 0, stream,
-                       (const bf16_t *)weight, wp, wtotal, a.Kg);
+    if (dma) {
+        const long wtotal = (long)g.Co * kpad;
+        hipLaunchKernelGGL(repack_w_blocked_kernel, dim3((unsigned)((wtotal + 255) / 256)), dim3(256), 0, stream,
+                           (const bf16_t *)weight, wp, wtotal, a.Kg, a.Cog);
+    } else {
+        const long wtotal = (long)g.Co * a.Kg;
+        hipLaunchKernelGGL(repack_w_kernel, dim3((unsigned)((wtotal + 255) / 256)), dim3(256), 0, stream,
+                           (const bf16_t *)weight, wp, wtotal, a.Kg);
+    }
     if (int rc = check_launch("repack_w")) return rc;
     a.weight = wp;
 
@@ -698,24 +744,24 @@ static int forward_16(const void *x, const void *weight, const void *bias, const
     const long tiles = (long)a.tiles_m * a.tiles_n;
     if (tiles >= (1L << 31)) return fail(DDCN_ERR_UNSUPPORTED, "16-bit path: too many GEMM tiles");
     const dim3 ggrid((unsigned)tiles, (unsigned)(g.N * g.groups));
-    // LDS-DMA ring (default 4 stages); DDCN_BF16_GEMM_STAGES=0 selects the register-staged kernel.  The DMA kernel
-    // addresses W and one (image, group) columns slab with 31-bit byte offsets.
-    const char *es = getenv("DDCN_BF16_GEMM_STAGES");
-    const int stages = es ? atoi(es) : 4;
-    const bool dma_ok = (long)a.Cog * a.Kg * 2 < (1L << 31) && (long)(a.Kg / 8) * a.P * 16 < (1L << 31);
+    const bool dma_ok = dma;
     // 256-row tiles (128x64 per wave) when Co fills them and they still give every CU two workgroups; DDCN_BF16_GEMM_MI forces 2 or 4
     const char *em = getenv("DDCN_BF16_GEMM_MI");
     const long tiles256 = (long)((a.Cog + 255) / 256) * a.tiles_n * g.N * g.groups;
-    const int mi = em ? atoi(em) : ((a.Cog >= 192 && tiles256 >= 512) ? 4 : 2);
-    if (dma_ok && mi == 4 && stages >= 2) {
+    // 256x256 tiles (8 waves) when they still give every CU a workgroup; DDCN_BF16_GEMM_MI=8 forces them
+    const long tiles_sq = (long)((a.Cog + 255) / 256) * ((a.P + 255) / 256) * g.N * g.groups;
+    const int mi = em ? atoi(em) : ((a.Cog >= 192 && tiles_sq >= 256) ? 8 : (a.Cog >= 192 && tiles256 >= 512) ? 4 : 2);
+    if (dma_ok && mi == 8 && stages >= 2) {
+        const dim3 g8((unsigned)((a.Cog + 255) / 256 * ((a.P + 255) / 256)), (unsigned)(g.N * g.groups));
+        static std::atomic<uint64_t> raised{0};   // 4 stages x 32 KiB
+        if (!raise_lds_limit((const void *)gemm16_dma_kernel<T, 4, 4, 4>, 4 * 32768, raised))
+            return fail(DDCN_ERR_LAUNCH, "gemm_16: cannot raise the LDS limit");
+        hipLaunchKernelGGL((gemm16_dma_kernel<T, 4, 4, 4>), g8, dim3(512), 4 * 32768, stream, a);
+    } else if (dma_ok && mi == 4 && stages >= 2) {
         const dim3 g4((unsigned)((a.Cog + 255) / 256 * a.tiles_n), (unsigned)(g.N * g.groups));
-        static bool attr = false;   // 3 stages x 24 KiB: above the 64 KiB default
-        if (!attr) {
-            if (hipFuncSetAttribute((const void *)gemm16_dma_kernel<T, 3, 4>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    3 * 24576) != hipSuccess)
-                return fail(DDCN_ERR_LAUNCH, "gemm_16: cannot raise the LDS limit");
-            attr = true;
-        }
+        static std::atomic<uint64_t> raised{0};   // 3 stages x 24 KiB: above the 64 KiB default
+        if (!raise_lds_limit((const void *)gemm16_dma_kernel<T, 3, 4>, 3 * 24576, raised))
+            return fail(DDCN_ERR_LAUNCH, "gemm_16: cannot raise the LDS limit");
         hipLaunchKernelGGL((gemm16_dma_kernel<T, 3, 4>), g4, dim3(GT), 3 * 24576, stream, a);
     } else if (dma_ok && stages == 2) hipLaunchKernelGGL((gemm16_dma_kernel<T, 2, 2>), ggrid, dim3(GT), 2 * 16384, stream, a);
     else if (dma_ok && stages == 3) hipLaunchKernelGGL((gemm16_dma_kernel<T, 3, 2>), ggrid, dim3(GT), 3 * 16384, stream, a);

@@ -4,6 +4,8 @@
 #include <stddef.h>
 #include <stdint.h>
 
+#include <atomic>
+
 #include "../../include/ddcn_hip.h"
 
 namespace ddcn {
@@ -13,6 +15,20 @@ int fail(int rc, const char *fmt, ...);
 int check_launch(const char *what);
 
 static inline size_t round_up(size_t v, size_t m) { return (v + m - 1) / m * m; }
+
+// Raises a kernel's dynamic-LDS limit once per device of the process (function attributes are per device; `done` is
+// a bit per device id, ids >= 64 set it every time).  Kept out of the per-call path so that nothing but launches runs
+// while a caller captures a HIP graph.  A race only repeats the (idempotent) call.
+static inline bool raise_lds_limit(const void *fn, int bytes, std::atomic<uint64_t> &done)
+{
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return false;
+    const uint64_t bit = dev < 64 ? (1ull << dev) : 0;
+    if (bit && (done.load(std::memory_order_acquire) & bit)) return true;
+    if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) != hipSuccess) return false;
+    done.fetch_or(bit, std::memory_order_release);
+    return true;
+}
 
 struct Dims {
     int K2, P, Ktot, Kg, Cg, Cog, cpg;

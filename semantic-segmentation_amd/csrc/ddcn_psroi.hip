@@ -552,13 +552,9 @@ static int psroi_forward(const T *data, const T *rois, const T *trans, T *out, T
     static const int env_plane = getenv("DDCN_PSROI_PLANE_FWD") ? atoi(getenv("DDCN_PSROI_PLANE_FWD")) : 1;
     if (env_plane && map_bytes <= (size_t)PLANE_LDS_MAX && a.PS * a.PS <= MAX_BINS && planes < (1L << 31) &&
         planes * ((a.R + 31) / 32) >= 256 && a.R <= 65535 * 32) {
-        static bool attr_set = false;
-        if (!attr_set) {
-            if (hipFuncSetAttribute((const void *)psroi_forward_plane_kernel<T>,
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, PLANE_LDS_MAX) != hipSuccess)
-                return fail(DDCN_ERR_LAUNCH, "psroi forward: cannot raise the LDS limit to %d bytes", PLANE_LDS_MAX);
-            attr_set = true;
-        }
+        static std::atomic<uint64_t> raised{0};   // one per instantiation (T)
+        if (!raise_lds_limit((const void *)psroi_forward_plane_kernel<T>, PLANE_LDS_MAX, raised))
+            return fail(DDCN_ERR_LAUNCH, "psroi forward: cannot raise the LDS limit to %d bytes", PLANE_LDS_MAX);
         long rs = (2048 + planes - 1) / planes;
         const long rs_max = (a.R + 31) / 32;
         if (rs > rs_max) rs = rs_max;
@@ -605,15 +601,10 @@ static int psroi_backward(const T *grad_out, const T *data, const T *rois, const
     const long planes = (long)a.B * a.C;
     const bool owner = plane_bytes <= (size_t)PLANE_LDS_MAX && planes < (1L << 31) && !getenv("DDCN_PSROI_ATOMIC");
     if (owner) {
-        static bool attr_set = false;  // idempotent: a race only repeats the call
-        if (!attr_set) {
-            if (hipFuncSetAttribute((const void *)psroi_backward_plane_kernel<T, false>,
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, PLANE_LDS_MAX) != hipSuccess ||
-                hipFuncSetAttribute((const void *)psroi_backward_plane_kernel<T, true>,
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, PLANE_LDS_MAX) != hipSuccess)
-                return fail(DDCN_ERR_LAUNCH, "psroi backward: cannot raise the LDS limit to %d bytes", PLANE_LDS_MAX);
-            attr_set = true;
-        }
+        static std::atomic<uint64_t> raised0{0}, raised1{0};
+        if (!raise_lds_limit((const void *)psroi_backward_plane_kernel<T, false>, PLANE_LDS_MAX, raised0) ||
+            !raise_lds_limit((const void *)psroi_backward_plane_kernel<T, true>, PLANE_LDS_MAX, raised1))
+            return fail(DDCN_ERR_LAUNCH, "psroi backward: cannot raise the LDS limit to %d bytes", PLANE_LDS_MAX);
         // RoI slices: enough workgroups to fill the chip, but each slice keeps >= 32 RoIs to amortise its plane
         long rs = (2048 + planes - 1) / planes;
         const long rs_max = (a.R + 31) / 32;
