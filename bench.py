@@ -109,7 +109,7 @@ def kernel_rooflines(w, tensors, iters):
     # HBM bytes per launch from the PMC passes committed under profiles/ (rocprofv3 cannot run inside this process);
     # they belong to the default workload only
     traffic = {}
-    tf = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01e_hbm_traffic.json")
+    tf = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01j_hbm_traffic.json")
     if os.path.exists(tf) and (w["N"], w["C"], w["Co"], w["H"], w["W"], w["dil"]) == (2, 512, 512, 97, 97, 4):
         with open(tf) as fh:
             traffic = {k: v["traffic_bytes"] for k, v in json.load(fh)["kernels"].items()}

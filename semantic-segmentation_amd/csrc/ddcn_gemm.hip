@@ -328,7 +328,18 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs &a, float *smem, int gr
 // Flat grid: the wide tiles of all slices first, then the narrow tiles, so that the last (partial) round of
 // workgroups is made of quarter-size tiles spread over every CU instead of a few full tiles on a few CUs.
 // A workgroup is two wave groups with one tile each (adjacent in the logical order).  Inside a class the m tile is
-// fastest: the tiles that share a B tile run back to back on one XCD's L2.
+// fastest within bands of MBAND m tiles: the tiles that share a B tile run back to back on one XCD's L2, and the A
+// slices of a band (8 x 128 rows x K) stay in that L2 while the band walks along n.  With all of a tall M in one band
+// (G2: 36 m tiles = 9.4 MB of W against 4 MB of L2) every n tile re-read W from the Infinity Cache.
+constexpr int MBAND = 8;
+__device__ __forceinline__ void band_order(int rem, int tiles_m, int tiles_n, int &tile_m, int &tile_n)
+{
+    const int per_band = MBAND * tiles_n;
+    const int band = rem / per_band, r2 = rem - band * per_band;
+    const int mcur = min(MBAND, tiles_m - band * MBAND);
+    tile_n = r2 / mcur;
+    tile_m = band * MBAND + (r2 - tile_n * mcur);
+}
 template <bool A_KC, bool B_KC, bool ATOMIC>
 __global__ __launch_bounds__(2 * NT) void gemm_f32_mfma(GemmArgs a)
 {
@@ -341,7 +352,8 @@ __global__ __launch_bounds__(2 * NT) void gemm_f32_mfma(GemmArgs a)
         idx = min(idx, a.total_big - 1);
         const int per_z = a.tiles_m * a.nb;
         const int z = idx / per_z, rem = idx - z * per_z;
-        const int tile_n = rem / a.tiles_m, tile_m = rem - tile_n * a.tiles_m;
+        int tile_m, tile_n;
+        band_order(rem, a.tiles_m, a.nb, tile_m, tile_n);
         gemm_tile<A_KC, B_KC, ATOMIC, BN>(a, smem, grp, valid, z, tile_m, tile_n * BN);
     } else {
         int idx = 2 * xcd_order(bid - a.blocks_big, a.blocks_nar) + grp;
@@ -349,7 +361,8 @@ __global__ __launch_bounds__(2 * NT) void gemm_f32_mfma(GemmArgs a)
         idx = min(idx, a.total_nar - 1);
         const int per_z = a.tiles_m * a.nn;
         const int z = idx / per_z, rem = idx - z * per_z;
-        const int tile_n = rem / a.tiles_m, tile_m = rem - tile_n * a.tiles_m;
+        int tile_m, tile_n;
+        band_order(rem, a.tiles_m, a.nn, tile_m, tile_n);
         gemm_tile<A_KC, B_KC, ATOMIC, BN_TAIL>(a, smem, grp, valid, z, tile_m, a.nb * BN + tile_n * BN_TAIL);
     }
 }
