@@ -566,37 +566,63 @@ void gemm16_dma_kernel(const Bf16Args a)
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
     const int r32 = lane & 31, hi = lane >> 5;
-#pragma unroll
-    for (int kt = 0; kt < NS - 1; ++kt)
-        if (kt < ntiles) request(kt);
-    for (int kt = 0; kt < ntiles; ++kt) {
-        // younger tiles still allowed in flight: RA + RB requests each
-        const int rem = min(NS - 2, ntiles - 1 - kt);
-        // one s_waitcnt: this wave's LDS reads of tile kt-1 are done (lgkmcnt 0) and its requests of tile kt have
-        // landed (vmcnt counts the requests that may stay in flight).  A plain __syncthreads() would drain vmcnt to 0.
-        if (rem >= 2) __builtin_amdgcn_s_waitcnt(wait_vm_lgkm0(2 * (RA + RB)));
-        else if (rem == 1) __builtin_amdgcn_s_waitcnt(wait_vm_lgkm0(RA + RB));
-        else __builtin_amdgcn_s_waitcnt(wait_vm_lgkm0(0));
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-        __builtin_amdgcn_sched_barrier(0);
-        if (kt + NS - 1 < ntiles) request(kt + NS - 1);
+    // fragments of one 16-k sub-step: MI of A, two of B
+    auto read_frags = [&](int kt, int s, u32x4 (&fa)[MI], u32x4 (&fb)[2]) {
         const u32x4 *As = ring + (kt % NS) * STAGE, *Bs = As + BMK * 4;
 #pragma unroll
-        for (int s = 0; s < DK / 16; ++s) {
-            u32x4 fa[MI], fb[2];
-#pragma unroll
-            for (int i = 0; i < MI; ++i) {
-                const int row = wm * (MI * 32) + i * 32 + r32;
-                fa[i] = As[row * 4 + ((s * 2 + hi) ^ ((row >> 2) & 3))];
-            }
-#pragma unroll
-            for (int j = 0; j < 2; ++j) fb[j] = Bs[(s * 2 + hi) * BNW + wn * 64 + j * 32 + r32];
-#pragma unroll
-            for (int i = 0; i < MI; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j) acc[i][j] = T::mfma(fa[i], fb[j], acc[i][j]);
+        for (int i = 0; i < MI; ++i) {
+            const int row = wm * (MI * 32) + i * 32 + r32;
+            fa[i] = As[row * 4 + ((s * 2 + hi) ^ ((row >> 2) & 3))];
         }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) fb[j] = Bs[(s * 2 + hi) * BNW + wn * 64 + j * 32 + r32];
+    };
+    auto mfmas = [&](const u32x4 (&fa)[MI], const u32x4 (&fb)[2]) {
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) acc[i][j] = T::mfma(fa[i], fb[j], acc[i][j]);
+    };
+    // one s_waitcnt: this wave's LDS reads are done (lgkmcnt 0) and all but its `tiles` youngest tile requests have
+    // landed (RA + RB requests per tile).  A plain __syncthreads() would drain vmcnt to 0.
+    auto wait_all_but = [&](int tiles) {
+        if (tiles >= 3) __builtin_amdgcn_s_waitcnt(wait_vm_lgkm0(3 * (RA + RB)));
+        else if (tiles == 2) __builtin_amdgcn_s_waitcnt(wait_vm_lgkm0(2 * (RA + RB)));
+        else if (tiles == 1) __builtin_amdgcn_s_waitcnt(wait_vm_lgkm0(RA + RB));
+        else __builtin_amdgcn_s_waitcnt(wait_vm_lgkm0(0));
+    };
+    static_assert(NS <= 4 && 3 * (RA + RB) < 64, "vmcnt is 6 bits and wait_all_but knows up to 3 tiles in flight");
+
+    // Software pipeline, two sub-steps of 16 k per tile.  The fragments of a sub-step are read one block of MFMAs
+    // before they are used, and the barrier that publishes tile kt+1 sits between the two MFMA blocks of tile kt:
+    //   read F(kt,1) | MFMA F(kt,0) | wait tile kt+1, barrier, request tile kt+NS into the stage of tile kt (every
+    //   wave has read all of it), read F(kt+1,0) | MFMA F(kt,1)
+    // so no MFMA waits for an LDS read issued right before it, and the ring holds NS tiles.
+    u32x4 fa0[MI], fb0[2], fa1[MI], fb1[2];
+#pragma unroll
+    for (int kt = 0; kt < NS; ++kt)
+        if (kt < ntiles) request(kt);
+    wait_all_but(min(NS - 1, ntiles - 1));
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    read_frags(0, 0, fa0, fb0);
+    for (int kt = 0; kt < ntiles; ++kt) {
+        read_frags(kt, 1, fa1, fb1);
+        __builtin_amdgcn_sched_barrier(0);
+        mfmas(fa0, fb0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (kt + 1 < ntiles) {
+            // requested so far: tiles 0 .. kt+NS-1; tile kt+1 must have landed
+            wait_all_but(min(NS - 2, ntiles - 2 - kt));
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            if (kt + NS < ntiles) request(kt + NS);
+            read_frags(kt + 1, 0, fa0, fb0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        mfmas(fa1, fb1);
+        __builtin_amdgcn_sched_barrier(0);
     }
 
     bf16_t *C = a.out + ((long)img * a.Co + (long)grp * M) * a.P;
