@@ -4,7 +4,7 @@
 // same K:569-632 (im2col) and H:430-435 (GEMM) as the fp32 path, with operands rounded to bf16.
 //
 // Columns layout: col[n][K/8][P][8] -- "k-octets": 8 consecutive k of one pixel are contiguous (16 bytes), consecutive
-// pixels follow.  That is exactly one B fragment of v_mfma_f32_32x32x16_bf16 per 16 bytes, so the GEMM needs no
+// pixels follow.  That is exactly one B fragment of v_mfma_f32_32x32x16_bf16 / 16x16x32_bf16 per 16 bytes, so the GEMM needs no
 // transpose anywhere, and both the im2col stores and the GEMM loads are coalesced along the pixel axis.  The k order
 // inside the path is (channel octet, tap, channel % 8) instead of the reference's (channel, tap): one tap of 8
 // channels is one octet, so a lane stores a finished 16-byte vector per tap.  The weights are repacked to the same
@@ -25,6 +25,9 @@
 //                 staged global -> registers -> LDS (W rows XOR-swizzled by 16-byte chunk, columns linear),
 //                 next tile's global loads in flight during the MFMAs, bias add and bf16 rounding in the epilogue.
 //                 Workgroups that share a columns tile are consecutive on one XCD (its L2 serves the re-reads).
+//   gemm16_dma    the default GEMM: operands global -> LDS by DMA through a ring of tiles of 32 k, weights repacked
+//                 per K step, 16x16x32 MFMAs, K loop software-pipelined across one barrier per tile; tiles of
+//                 128x128, 256x128 (4 waves) or 256x256 (8 waves).
 #include "ddcn_common.h"
 
 #include <stdlib.h>
@@ -39,11 +42,13 @@ typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
 typedef __attribute__((ext_vector_type(2))) _Float16 f16x2;
 typedef __attribute__((ext_vector_type(2))) float f32x2;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
 
 // The 16-bit format of a call: storage is always unsigned short at the boundary.  one(): element -> float;
 // lo()/hi(): the two elements of a packed register; T::pack2(): two floats -> packed pair, round to nearest even
-// (v_cvt_pk_bf16_f32 / v_cvt_f16_f32 + pack on gfx950); mfma(): one 32x32x16 step with fp32 accumulation.
+// (v_cvt_pk_bf16_f32 / v_cvt_f16_f32 + pack on gfx950); mfma() / mfma16(): one 32x32x16 / 16x16x32 step with fp32
+// accumulation (register-staged GEMM / LDS-DMA GEMMs).
 struct BF16 {
     static __device__ __forceinline__ float one(bf16_t v) { return __uint_as_float((unsigned)v << 16); }
     static __device__ __forceinline__ float lo(unsigned u) { return __uint_as_float(u << 16); }
@@ -57,6 +62,10 @@ struct BF16 {
     {
         return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c,
                                                        0, 0, 0);
+    }
+    static __device__ __forceinline__ f32x4 mfma16(u32x4 a, u32x4 b, f32x4 c)
+    {
+        return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
     }
 };
 struct F16 {
@@ -72,6 +81,10 @@ struct F16 {
     {
         return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c,
                                                       0, 0, 0);
+    }
+    static __device__ __forceinline__ f32x4 mfma16(u32x4 a, u32x4 b, f32x4 c)
+    {
+        return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
     }
 };
 
@@ -493,6 +506,10 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t uniform_rsrc(const void *p, un
                                              __builtin_amdgcn_readfirstlane(bytes), 0x00020000);
 }
 
+// LDS slot of k chunk c in a 64-byte A row: c ^ a_swizzle(row).  The table (0, 2, 3, 1) over the row quad makes the
+// 16x16x32 fragment read (lane l: row l % 16, chunk l / 16) conflict-free in every 16-lane group of ds_read_b128.
+__device__ __forceinline__ int a_swizzle(int row) { return (0x78 >> (2 * ((row >> 2) & 3))) & 3; }
+
 // MI = 32-row MFMA tiles per wave along M: 2 -> 128-row workgroup tile (64x64 per wave, one fragment read per MFMA),
 // 4 -> 256-row tile (128x64 per wave: 6 fragment reads per 8 MFMAs, the LDS pipe stops being the co-bottleneck).
 constexpr unsigned wait_vm_lgkm0(int vm) { return (unsigned)((vm & 0xF) | ((vm >> 4) << 14) | 0x0070); }
@@ -532,7 +549,7 @@ void gemm16_dma_kernel(const Bf16Args a)
 #pragma unroll
     for (int r = 0; r < RA; ++r) {
         const int q = (r * NWAVES + wave) * 64 + lane;
-        const int row = q >> 2, c = (q & 3) ^ ((row >> 2) & 3);
+        const int row = q >> 2, c = (q & 3) ^ a_swizzle(row);
         offA[r] = (m0 + row < M) ? (unsigned)(((m0 + row) * DK + c * 8) * 2) : DMA_OOB;
     }
 #pragma unroll
@@ -557,31 +574,37 @@ void gemm16_dma_kernel(const Bf16Args a)
         }
     };
 
-    f32x16 acc[MI][2];
+    // v_mfma_f32_16x16x32: one instruction spans the 32 k of a tile; the wave's MI*32 x 64 block is 2*MI x 4 tiles of
+    // 16 x 16 (the guide measures this form at 1.15 x the FLOP/s of 32x32x16 at the clock the chip holds under load)
+    constexpr int RB16 = 2 * MI;
+    f32x4 acc[RB16][4];
 #pragma unroll
-    for (int i = 0; i < MI; ++i)
+    for (int i = 0; i < RB16; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < 4; ++j)
 #pragma unroll
-            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+            for (int e = 0; e < 4; ++e) acc[i][j][e] = 0.f;
 
-    const int r32 = lane & 31, hi = lane >> 5;
-    // fragments of one 16-k sub-step: MI of A, two of B
-    auto read_frags = [&](int kt, int s, u32x4 (&fa)[MI], u32x4 (&fb)[2]) {
-        const u32x4 *As = ring + (kt % NS) * STAGE, *Bs = As + BMK * 4;
+    const int r16 = lane & 15, kc = lane >> 4;
+    // A fragments of one half of the wave's rows (MI tiles of 16 rows), B fragments of its four column tiles
+    auto read_a = [&](int kt, int half, u32x4 (&fa)[MI]) {
+        const u32x4 *As = ring + (kt % NS) * STAGE;
 #pragma unroll
         for (int i = 0; i < MI; ++i) {
-            const int row = wm * (MI * 32) + i * 32 + r32;
-            fa[i] = As[row * 4 + ((s * 2 + hi) ^ ((row >> 2) & 3))];
+            const int row = wm * (MI * 32) + (half * MI + i) * 16 + r16;
+            fa[i] = As[row * 4 + (kc ^ a_swizzle(row))];
         }
-#pragma unroll
-        for (int j = 0; j < 2; ++j) fb[j] = Bs[(s * 2 + hi) * BNW + wn * 64 + j * 32 + r32];
     };
-    auto mfmas = [&](const u32x4 (&fa)[MI], const u32x4 (&fb)[2]) {
+    auto read_b = [&](int kt, u32x4 (&fb)[4]) {
+        const u32x4 *Bs = ring + (kt % NS) * STAGE + BMK * 4;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) fb[j] = Bs[kc * BNW + wn * 64 + j * 16 + r16];
+    };
+    auto mfmas = [&](int half, const u32x4 (&fa)[MI], const u32x4 (&fb)[4]) {
 #pragma unroll
         for (int i = 0; i < MI; ++i)
 #pragma unroll
-            for (int j = 0; j < 2; ++j) acc[i][j] = T::mfma(fa[i], fb[j], acc[i][j]);
+            for (int j = 0; j < 4; ++j) acc[half * MI + i][j] = T::mfma16(fa[i], fb[j], acc[half * MI + i][j]);
     };
     // one s_waitcnt: this wave's LDS reads are done (lgkmcnt 0) and all but its `tiles` youngest tile requests have
     // landed (RA + RB requests per tile).  A plain __syncthreads() would drain vmcnt to 0.
@@ -593,23 +616,17 @@ void gemm16_dma_kernel(const Bf16Args a)
     };
     static_assert(NS <= 4 && 3 * (RA + RB) < 64, "vmcnt is 6 bits and wait_all_but knows up to 3 tiles in flight");
 
-    // Software pipeline, two sub-steps of 16 k per tile.  The fragments of a sub-step are read one block of MFMAs
-    // before they are used, and the barrier that publishes tile kt+1 sits between the two MFMA blocks of tile kt:
-    //   read F(kt,1) | MFMA F(kt,0) | wait tile kt+1, barrier, request tile kt+NS into the stage of tile kt (every
-    //   wave has read all of it), read F(kt+1,0) | MFMA F(kt,1)
-    // so no MFMA waits for an LDS read issued right before it, and the ring holds NS tiles.
-    u32x4 fa0[MI], fb0[2], fa1[MI], fb1[2];
-#pragma unroll
-    for (int kt = 0; kt < NS; ++kt)
-        if (kt < ntiles) request(kt);
-    wait_all_but(min(NS - 1, ntiles - 1));
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-    read_frags(0, 0, fa0, fb0);
-    for (int kt = 0; kt < ntiles; ++kt) {
-        read_frags(kt, 1, fa1, fb1);
+    // Software pipeline over the two row halves of a tile.  Fragments are read one block of MFMAs before they are
+    // used, and the barrier that publishes tile kt+1 sits between the two MFMA blocks of tile kt:
+    //   read A1(kt) | MFMA A0(kt) x B(kt) | wait tile kt+1, barrier, request tile kt+NS into the stage of tile kt
+    //   (every wave has read all of it), read B(kt+1), A0(kt+1) | MFMA A1(kt) x B(kt)
+    // so no MFMA waits for an LDS read issued right before it, and the ring holds NS tiles.  The loop is unrolled by
+    // two so that the B fragments alternate between two register sets.
+    u32x4 fa0[MI], fa1[MI], fbx[4], fby[4];
+    auto step = [&](int kt, u32x4 (&fbc)[4], u32x4 (&fbn)[4]) {
+        read_a(kt, 1, fa1);
         __builtin_amdgcn_sched_barrier(0);
-        mfmas(fa0, fb0);
+        mfmas(0, fa0, fbc);
         __builtin_amdgcn_sched_barrier(0);
         if (kt + 1 < ntiles) {
             // requested so far: tiles 0 .. kt+NS-1; tile kt+1 must have landed
@@ -618,25 +635,39 @@ void gemm16_dma_kernel(const Bf16Args a)
             asm volatile("" ::: "memory");
             __builtin_amdgcn_sched_barrier(0);
             if (kt + NS < ntiles) request(kt + NS);
-            read_frags(kt + 1, 0, fa0, fb0);
+            read_b(kt + 1, fbn);
+            read_a(kt + 1, 0, fa0);
             __builtin_amdgcn_sched_barrier(0);
         }
-        mfmas(fa1, fb1);
+        mfmas(1, fa1, fbc);
         __builtin_amdgcn_sched_barrier(0);
+    };
+#pragma unroll
+    for (int kt = 0; kt < NS; ++kt)
+        if (kt < ntiles) request(kt);
+    wait_all_but(min(NS - 1, ntiles - 1));
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    read_b(0, fbx);
+    read_a(0, 0, fa0);
+    for (int kt = 0; kt < ntiles; kt += 2) {
+        step(kt, fbx, fby);
+        if (kt + 1 < ntiles) step(kt + 1, fby, fbx);
     }
 
+    // lane l holds rows 4*(l/16) + e, column l % 16 of each 16 x 16 tile
     bf16_t *C = a.out + ((long)img * a.Co + (long)grp * M) * a.P;
     const bf16_t *bias = a.bias ? a.bias + grp * M : nullptr;
 #pragma unroll
-    for (int i = 0; i < MI; ++i) {
+    for (int i = 0; i < RB16; ++i) {
 #pragma unroll
-        for (int e = 0; e < 16; ++e) {
-            const int row = m0 + wm * (MI * 32) + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * hi;
+        for (int e = 0; e < 4; ++e) {
+            const int row = m0 + wm * (MI * 32) + i * 16 + kc * 4 + e;
             if (row >= M) continue;
             const float bv = bias ? T::one(bias[row]) : 0.f;
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const int col = n0 + wn * 64 + j * 32 + r32;
+            for (int j = 0; j < 4; ++j) {
+                const int col = n0 + wn * 64 + j * 16 + r16;
                 const float v = acc[i][j][e] + bv;
                 if (col < a.P) C[(long)row * a.P + col] = (bf16_t)T::pack2(v, 0.f);
             }
