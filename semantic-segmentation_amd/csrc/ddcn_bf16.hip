@@ -133,12 +133,19 @@ __device__ __forceinline__ u32x4 sample_octet_global(const bf16_t *xb, long HW, 
     const int hc0 = min(max(hl, 0), H - 1), hc1 = min(max(hl + 1, 0), H - 1);
     const int wc0 = min(max(wl, 0), W - 1), wc1 = min(max(wl + 1, 0), W - 1);
     const int i1 = hc0 * W + wc0, i2 = hc0 * W + wc1, i3 = hc1 * W + wc0, i4 = hc1 * W + wc1;
-    float v[8];
+    // All 32 loads are unconditional (the addresses are clamped into the map) and issued before the first use: a
+    // load under a condition becomes a branch with its own wait, 32 memory latencies in a row.
+    bf16_t raw[8][4];
 #pragma unroll
     for (int c = 0; c < 8; ++c) {
         const bf16_t *pl = xb + c * HW;
-        const float x1 = (t && l) ? T::one(pl[i1]) : 0.f, x2 = (t && r) ? T::one(pl[i2]) : 0.f;
-        const float x3 = (b && l) ? T::one(pl[i3]) : 0.f, x4 = (b && r) ? T::one(pl[i4]) : 0.f;
+        raw[c][0] = pl[i1]; raw[c][1] = pl[i2]; raw[c][2] = pl[i3]; raw[c][3] = pl[i4];
+    }
+    float v[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        const float x1 = (t && l) ? T::one(raw[c][0]) : 0.f, x2 = (t && r) ? T::one(raw[c][1]) : 0.f;
+        const float x3 = (b && l) ? T::one(raw[c][2]) : 0.f, x4 = (b && r) ? T::one(raw[c][3]) : 0.f;
         v[c] = w1 * x1 + w2 * x2 + w3 * x3 + w4 * x4;
     }
     u32x4 o;
@@ -278,35 +285,24 @@ __global__ __launch_bounds__(IT, 2) void im2col_bf16_tile_kernel(const Bf16Args 
     }
 
     u32x4 *buf0 = patch, *buf1 = patch + a.RS;
-    u32x4 stg[NCELL];
+    // Staging registers hold what the loads return, untouched, until stage_store: any use of them (packing included)
+    // right after the loads would make the compiler wait for the loads before the sampling they are meant to overlap.
+    // PAIR: 8 dwords per unit (one per channel, two cells each); else 8 halfwords per cell, packed late as well.
+    constexpr int NSTG = PAIR ? NUNIT * 8 : NCELL * 8;
+    unsigned stg[NSTG];
     auto stage_load = [&](int c0) {   // c0 relative to c_begin
         if constexpr (PAIR) {
 #pragma unroll
-            for (int j = 0; j < NUNIT; ++j) {
-                unsigned d[8];
+            for (int j = 0; j < NUNIT; ++j)
 #pragma unroll
                 for (int c = 0; c < 8; ++c)
-                    d[c] = soff[j] >= 0 ? *(const unsigned *)(xb + (long)(c0 + c) * HW + soff[j]) : 0u;
-                stg[2 * j].x = (d[0] & 0xffffu) | (d[1] << 16);
-                stg[2 * j].y = (d[2] & 0xffffu) | (d[3] << 16);
-                stg[2 * j].z = (d[4] & 0xffffu) | (d[5] << 16);
-                stg[2 * j].w = (d[6] & 0xffffu) | (d[7] << 16);
-                stg[2 * j + 1].x = (d[0] >> 16) | (d[1] & 0xffff0000u);
-                stg[2 * j + 1].y = (d[2] >> 16) | (d[3] & 0xffff0000u);
-                stg[2 * j + 1].z = (d[4] >> 16) | (d[5] & 0xffff0000u);
-                stg[2 * j + 1].w = (d[6] >> 16) | (d[7] & 0xffff0000u);
-            }
+                    stg[j * 8 + c] = soff[j] >= 0 ? *(const unsigned *)(xb + (long)(c0 + c) * HW + soff[j]) : 0u;
         } else {
 #pragma unroll
-            for (int j = 0; j < NCELL; ++j) {
-                unsigned short v[8];
+            for (int j = 0; j < NCELL; ++j)
 #pragma unroll
-                for (int c = 0; c < 8; ++c) v[c] = soff[j] >= 0 ? xb[(long)(c0 + c) * HW + soff[j]] : (unsigned short)0;
-                stg[j].x = v[0] | ((unsigned)v[1] << 16);
-                stg[j].y = v[2] | ((unsigned)v[3] << 16);
-                stg[j].z = v[4] | ((unsigned)v[5] << 16);
-                stg[j].w = v[6] | ((unsigned)v[7] << 16);
-            }
+                for (int c = 0; c < 8; ++c)
+                    stg[j * 8 + c] = soff[j] >= 0 ? (unsigned)xb[(long)(c0 + c) * HW + soff[j]] : 0u;
         }
     };
     auto stage_store = [&](u32x4 *buf) {
@@ -314,15 +310,32 @@ __global__ __launch_bounds__(IT, 2) void im2col_bf16_tile_kernel(const Bf16Args 
 #pragma unroll
             for (int j = 0; j < NUNIT; ++j) {
                 const int i = (t + IT * j) * 2;
+                const unsigned *d = stg + j * 8;
                 if (i < a.RS) {
-                    buf[i] = stg[2 * j];
-                    buf[i + 1] = stg[2 * j + 1];
+                    u32x4 lo, hi;
+                    lo.x = (d[0] & 0xffffu) | (d[1] << 16);
+                    lo.y = (d[2] & 0xffffu) | (d[3] << 16);
+                    lo.z = (d[4] & 0xffffu) | (d[5] << 16);
+                    lo.w = (d[6] & 0xffffu) | (d[7] << 16);
+                    hi.x = (d[0] >> 16) | (d[1] & 0xffff0000u);
+                    hi.y = (d[2] >> 16) | (d[3] & 0xffff0000u);
+                    hi.z = (d[4] >> 16) | (d[5] & 0xffff0000u);
+                    hi.w = (d[6] >> 16) | (d[7] & 0xffff0000u);
+                    buf[i] = lo;
+                    buf[i + 1] = hi;
                 }
             }
         } else {
 #pragma unroll
-            for (int j = 0; j < NCELL; ++j)
-                if (t + IT * j < a.RS) buf[t + IT * j] = stg[j];
+            for (int j = 0; j < NCELL; ++j) {
+                const unsigned *v = stg + j * 8;
+                u32x4 o;
+                o.x = v[0] | (v[1] << 16);
+                o.y = v[2] | (v[3] << 16);
+                o.z = v[4] | (v[5] << 16);
+                o.w = v[6] | (v[7] << 16);
+                if (t + IT * j < a.RS) buf[t + IT * j] = o;
+            }
         }
     };
 
@@ -364,6 +377,7 @@ __global__ __launch_bounds__(IT, 2) void im2col_bf16_tile_kernel(const Bf16Args 
             const float h = (float)(ho * a.sh - a.ph + (k / 3) * a.dh) + T::one(offb[(long)(2 * k) * a.P]);
             const float w = (float)(wo * a.sw - a.pw + (k % 3) * a.dw) + T::one(offb[(long)(2 * k + 1) * a.P]);
             const float m = MOD ? T::one(a.mask[(((long)n * a.dg + dgi) * 9 + k) * a.P + p]) : 1.f;
+#pragma unroll 2
             for (int oc = 0; oc < nocts; ++oc)
                 colp[((long)oc * 9 + k) * a.P] = sample_octet_global<T>(xb + (long)oc * 8 * HW, HW, a.H, a.W, h, w, m);
         }

@@ -338,22 +338,36 @@ __global__ __launch_bounds__(ST, SC == 4 ? 2 : DDCN_S9_WPS) void col2im_coord_ti
             const float lh = flh[k], lw = flw[k];
             const float hh = 1.f - lh, hw = 1.f - lw;
             const float w1 = hh * hw, w2 = hh * lw, w3 = lh * hw, w4 = lh * lw;
-            const float *im = a.x + ((long)n * g.C + cg0) * HW + gi;
-            float *gim = gxn + (long)cg0 * HW + gi;
+            // Corner offsets inside a channel plane, 0 for a corner outside the map: every load below is
+            // unconditional and four channels' loads are issued before the first use (a load under a condition
+            // becomes a branch with its own wait: five memory latencies in a row per channel).
+            const int o1 = ok1 ? gi : 0, o2 = ok2 ? gi + 1 : 0, o3 = ok3 ? gi + g.W : 0, o4 = ok4 ? gi + g.W + 1 : 0;
+            const float *im = a.x + ((long)n * g.C + cg0) * HW;
+            float *gim = gxn + (long)cg0 * HW;
             const float *gcp = a.gcol + (((long)n * g.C + cg0) * K2 + k) * a.ld + p;
-            for (int c = 0; c < a.CG; ++c) {
-                const float gc = gcp[(long)c * K2 * a.ld];
-                const float v1 = ok1 ? im[0] : 0.f;
-                const float v2 = ok2 ? im[1] : 0.f;
-                const float v3 = ok3 ? im[g.W] : 0.f;
-                const float v4 = ok4 ? im[g.W + 1] : 0.f;
-                S1[k] += gc * v1; S2[k] += gc * v2; S3[k] += gc * v3; S4[k] += gc * v4;
-                const float tg = MOD ? gc * fm[k] : gc;
-                if (ok1) atomicAdd(gim, w1 * tg);
-                if (ok2) atomicAdd(gim + 1, w2 * tg);
-                if (ok3) atomicAdd(gim + g.W, w3 * tg);
-                if (ok4) atomicAdd(gim + g.W + 1, w4 * tg);
-                im += HW; gim += HW;
+            for (int c0 = 0; c0 < a.CG; c0 += 4) {
+                float gc[4], r1[4], r2[4], r3[4], r4[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int c = min(c0 + u, a.CG - 1);
+                    gc[u] = gcp[(long)c * K2 * a.ld];
+                    r1[u] = im[(long)c * HW + o1]; r2[u] = im[(long)c * HW + o2];
+                    r3[u] = im[(long)c * HW + o3]; r4[u] = im[(long)c * HW + o4];
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    if (c0 + u < a.CG) {
+                        const float v1 = ok1 ? r1[u] : 0.f, v2 = ok2 ? r2[u] : 0.f;
+                        const float v3 = ok3 ? r3[u] : 0.f, v4 = ok4 ? r4[u] : 0.f;
+                        S1[k] += gc[u] * v1; S2[k] += gc[u] * v2; S3[k] += gc[u] * v3; S4[k] += gc[u] * v4;
+                        const float tg = MOD ? gc[u] * fm[k] : gc[u];
+                        float *gq = gim + (long)(c0 + u) * HW;
+                        if (ok1) atomicAdd(gq + o1, w1 * tg);
+                        if (ok2) atomicAdd(gq + o2, w2 * tg);
+                        if (ok3) atomicAdd(gq + o3, w3 * tg);
+                        if (ok4) atomicAdd(gq + o4, w4 * tg);
+                    }
+                }
             }
         }
     }
