@@ -258,24 +258,38 @@ __global__ __launch_bounds__(IT, 2) void im2col_tile_kernel(Im2colTileArgs a)
                 const int hl = ghw[k] >> 16, wl = (int)(short)(ghw[k] & 0xffff);
                 const bool ok1 = hl >= 0 && wl >= 0, ok2 = hl >= 0 && wl + 1 <= g.W - 1;
                 const bool ok3 = hl + 1 <= g.H - 1 && wl >= 0, ok4 = hl + 1 <= g.H - 1 && wl + 1 <= g.W - 1;
-                const float *im = a.x + ((long)n * g.C + cg0) * HW + hl * g.W + wl;
+                // corner offsets inside a channel plane, 0 for a corner outside the map: the loads are unconditional
+                // and four channels' loads are issued before the first use (a load under a condition becomes a
+                // branch with its own wait)
+                const int gi = hl * g.W + wl;
+                const int o1 = ok1 ? gi : 0, o2 = ok2 ? gi + 1 : 0, o3 = ok3 ? gi + g.W : 0, o4 = ok4 ? gi + g.W + 1 : 0;
+                const float *im = a.x + ((long)n * g.C + cg0) * HW;
                 const float w1 = bw1[k], w2 = bw2[k], w3 = bw3[k], w4 = bw4[k];
-                for (int c = 0; c < a.CG; ++c) {
-                    const float v1 = ok1 ? im[0] : 0.f;
-                    const float v2 = ok2 ? im[1] : 0.f;
-                    const float v3 = ok3 ? im[g.W] : 0.f;
-                    const float v4 = ok4 ? im[g.W + 1] : 0.f;
-                    float val = (w1 * v1 + w2 * v2 + w3 * v3 + w4 * v4);
-                    if (MOD) val = val * fm[k];
-                    if (SKW) {
+                for (int c0 = 0; c0 < a.CG; c0 += 4) {
+                    float r1[4], r2[4], r3[4], r4[4];
 #pragma unroll
-                        for (int co = 0; co < SKW; ++co)
-                            if (co < a.sk_co) sacc[co] += a.sk_w[((long)co * g.C + cg0 + c) * K2 + k] * val;
-                    } else {
-                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, val), rcol, pvo,
-                                                              (unsigned)(((cg0 + c) * K2 + k) * a.ld * 4), 0);
+                    for (int u = 0; u < 4; ++u) {
+                        const float *pl = im + (long)min(c0 + u, a.CG - 1) * HW;
+                        r1[u] = pl[o1]; r2[u] = pl[o2]; r3[u] = pl[o3]; r4[u] = pl[o4];
                     }
-                    im += HW;
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int c = c0 + u;
+                        if (c < a.CG) {
+                            const float v1 = ok1 ? r1[u] : 0.f, v2 = ok2 ? r2[u] : 0.f;
+                            const float v3 = ok3 ? r3[u] : 0.f, v4 = ok4 ? r4[u] : 0.f;
+                            float val = (w1 * v1 + w2 * v2 + w3 * v3 + w4 * v4);
+                            if (MOD) val = val * fm[k];
+                            if (SKW) {
+#pragma unroll
+                                for (int co = 0; co < SKW; ++co)
+                                    if (co < a.sk_co) sacc[co] += a.sk_w[((long)co * g.C + cg0 + c) * K2 + k] * val;
+                            } else {
+                                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, val), rcol, pvo,
+                                                                      (unsigned)(((cg0 + c) * K2 + k) * a.ld * 4), 0);
+                            }
+                        }
+                    }
                 }
             }
         }
