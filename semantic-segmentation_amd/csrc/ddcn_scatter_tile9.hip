@@ -113,14 +113,23 @@ __global__ __launch_bounds__(ST, SC == 4 ? 2 : DDCN_S9_WPS) void col2im_coord_ti
         const float *off = a.offset + ((long)n * g.dg + dgi) * 2 * K2 * a.P + p;
         const float *msk = MOD ? a.mask + ((long)n * g.dg + dgi) * K2 * a.P + p : nullptr;
         const int h_in = ho * g.sh - g.ph, w_in = wo * g.sw - g.pw;
+        // all 27 values in flight before the first use (p is 0 for a dead lane: the loads are unconditional; a load
+        // under `if (live)` becomes a branch and a wait per tap)
+        float roh[K2], row_[K2], rm[K2];
+#pragma unroll
+        for (int k = 0; k < K2; ++k) {
+            roh[k] = off[(long)(2 * k) * a.P];
+            row_[k] = off[(long)(2 * k + 1) * a.P];
+            rm[k] = MOD ? msk[(long)k * a.P] : 1.f;
+        }
 #pragma unroll
         for (int k = 0; k < K2; ++k) {
             const int i = k / 3, j = k - 3 * i;
             float h = -2.f, w = -2.f, m = 1.f;
             if (live) {
-                h = (float)(h_in + i * g.dh) + off[(long)(2 * k) * a.P];
-                w = (float)(w_in + j * g.dw) + off[(long)(2 * k + 1) * a.P];
-                if (MOD) m = msk[(long)k * a.P];
+                h = (float)(h_in + i * g.dh) + roh[k];
+                w = (float)(w_in + j * g.dw) + row_[k];
+                if (MOD) m = rm[k];
             }
             const float fhl = floorf(h), fwl = floorf(w);
             flh[k] = h - fhl; flw[k] = w - fwl; fm[k] = m;
