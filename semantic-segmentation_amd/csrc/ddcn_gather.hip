@@ -79,10 +79,13 @@ __global__ __launch_bounds__(GT) void im2col_kernel(GatherArgs a)
         const float w1 = hh * hw, w2 = hh * lw, w3 = lh * hw, w4 = lh * lw;
         for (int c = 0; c < a.CH; ++c) {
             const float *im = xb + c * HW;
-            const float v1 = s.ok1 ? im[s.i1] : 0.f;
-            const float v2 = s.ok2 ? im[s.i2] : 0.f;
-            const float v3 = s.ok3 ? im[s.i3] : 0.f;
-            const float v4 = s.ok4 ? im[s.i4] : 0.f;
+            // i1..i4 are 0 for a corner outside the map: unconditional loads, one wait for the four (a load under a
+            // condition becomes a branch with a wait of its own)
+            const float r1 = im[s.i1], r2 = im[s.i2], r3 = im[s.i3], r4 = im[s.i4];
+            const float v1 = s.ok1 ? r1 : 0.f;
+            const float v2 = s.ok2 ? r2 : 0.f;
+            const float v3 = s.ok3 ? r3 : 0.f;
+            const float v4 = s.ok4 ? r4 : 0.f;
             float val = (w1 * v1 + w2 * v2 + w3 * v3 + w4 * v4);
             if (msk) val = val * m;
             colb[((long)c * a.K2 + k) * a.ld] = val;
@@ -143,10 +146,11 @@ __global__ __launch_bounds__(GT) void col2im_coord_kernel(GatherArgs a)
                 for (int c = slice; c < a.CH; c += 4) {
                     const float *im = xb + c * HW;
                     const float gc = gcb[((long)c * a.K2 + k) * a.ld];
-                    const float v1 = s.ok1 ? im[s.i1] : 0.f;
-                    const float v2 = s.ok2 ? im[s.i2] : 0.f;
-                    const float v3 = s.ok3 ? im[s.i3] : 0.f;
-                    const float v4 = s.ok4 ? im[s.i4] : 0.f;
+                    const float r1 = im[s.i1], r2 = im[s.i2], r3 = im[s.i3], r4 = im[s.i4];   // i* = 0 when outside
+                    const float v1 = s.ok1 ? r1 : 0.f;
+                    const float v2 = s.ok2 ? r2 : 0.f;
+                    const float v3 = s.ok3 ? r3 : 0.f;
+                    const float v4 = s.ok4 ? r4 : 0.f;
                     float wh_ = 0.f, ww_ = 0.f;
                     wh_ += -1.f * cwl * v1; wh_ += -1.f * cwh * v2; wh_ += cwl * v3; wh_ += cwh * v4;
                     ww_ += -1.f * chl * v1; ww_ += chl * v2; ww_ += -1.f * chh * v3; ww_ += chh * v4;

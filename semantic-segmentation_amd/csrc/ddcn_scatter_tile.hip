@@ -100,12 +100,15 @@ __global__ __launch_bounds__(TT) void col2im_coord_tile_kernel(TileArgs a)
                 const float *gck = gcb + (long)k * a.ld;
 #pragma unroll 4
                 for (int cc = 0; cc < a.CC; ++cc) {
-                    const float *im = xb + cc * HW + gi;
+                    // corner offsets are 0 for a corner outside the map: unconditional loads, one wait for the four
+                    const float *im = xb + cc * HW;
                     const float gc = gck[(long)cc * K2 * a.ld];
-                    const float v1 = ok1 ? im[0] : 0.f;
-                    const float v2 = ok2 ? im[1] : 0.f;
-                    const float v3 = ok3 ? im[g.W] : 0.f;
-                    const float v4 = ok4 ? im[g.W + 1] : 0.f;
+                    const float r1 = im[ok1 ? gi : 0], r2 = im[ok2 ? gi + 1 : 0];
+                    const float r3 = im[ok3 ? gi + g.W : 0], r4 = im[ok4 ? gi + g.W + 1 : 0];
+                    const float v1 = ok1 ? r1 : 0.f;
+                    const float v2 = ok2 ? r2 : 0.f;
+                    const float v3 = ok3 ? r3 : 0.f;
+                    const float v4 = ok4 ? r4 : 0.f;
                     float wh = 0.f, ww = 0.f;
                     wh += -1.f * cwl * v1; wh += -1.f * cwh * v2; wh += cwl * v3; wh += cwh * v4;
                     ww += -1.f * chl * v1; ww += chl * v2; ww += -1.f * chh * v3; ww += chh * v4;
