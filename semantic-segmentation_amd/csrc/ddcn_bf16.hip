@@ -367,7 +367,15 @@ __global__ __launch_bounds__(IT, 2) void im2col_bf16_tile_kernel(const Bf16Args 
         if (oc + 1 < nocts) stage_store(nxt);
         __syncthreads();
     }
-    // second pass: samples whose corners leave the staged patch, from global memory with the reference's guards
+    // Second pass: samples whose corners leave the staged patch, from global memory with the reference's guards.
+    // Few lanes hold one (0.5 % of the samples at sigma 2) but almost every wave does, and a wave that walks its own
+    // escapees runs the 32-load gather per octet for one or two live lanes.  So the workgroup first lists its
+    // escapees in LDS (the patch buffers are free now: slot 0 = counter, then {p | k << 27, h, w, mask} per escapee),
+    // then deals (escapee, octet) items to all 256 lanes.  Escapees beyond the list's capacity stay with their lane.
+    unsigned *cnt = (unsigned *)patch;
+    const unsigned cap = (unsigned)(2 * a.RS - 1);
+    if (t == 0) *cnt = 0u;
+    __syncthreads();
     if (live) {
 #pragma unroll
         for (int k = 0; k < 9; ++k) {
@@ -377,10 +385,30 @@ __global__ __launch_bounds__(IT, 2) void im2col_bf16_tile_kernel(const Bf16Args 
             const float h = (float)(ho * a.sh - a.ph + (k / 3) * a.dh) + T::one(offb[(long)(2 * k) * a.P]);
             const float w = (float)(wo * a.sw - a.pw + (k % 3) * a.dw) + T::one(offb[(long)(2 * k + 1) * a.P]);
             const float m = MOD ? T::one(a.mask[(((long)n * a.dg + dgi) * 9 + k) * a.P + p]) : 1.f;
+            const unsigned slot = atomicAdd(cnt, 1u);
+            if (slot < cap) {
+                u32x4 e;
+                e.x = (unsigned)p | ((unsigned)k << 27);
+                e.y = __float_as_uint(h); e.z = __float_as_uint(w); e.w = __float_as_uint(m);
+                patch[1 + slot] = e;
+            } else {
 #pragma unroll 2
-            for (int oc = 0; oc < nocts; ++oc)
-                colp[((long)oc * 9 + k) * a.P] = sample_octet_global<T>(xb + (long)oc * 8 * HW, HW, a.H, a.W, h, w, m);
+                for (int oc = 0; oc < nocts; ++oc)
+                    colp[((long)oc * 9 + k) * a.P] =
+                        sample_octet_global<T>(xb + (long)oc * 8 * HW, HW, a.H, a.W, h, w, m);
+            }
         }
+    }
+    __syncthreads();
+    const int listed = (int)min(*cnt, cap);
+    u32x4 *colg = (u32x4 *)a.col + ((long)n * a.KO + (long)(c_begin / 8) * 9) * a.P;
+    for (int it = t; it < listed * nocts; it += IT) {
+        const int oc = it / listed, ei = it - oc * listed;
+        const u32x4 e = patch[1 + ei];
+        const int ep = (int)(e.x & 0x7ffffffu), k = (int)(e.x >> 27);
+        colg[((long)oc * 9 + k) * a.P + ep] = sample_octet_global<T>(xb + (long)oc * 8 * HW, HW, a.H, a.W,
+                                                                    __uint_as_float(e.y), __uint_as_float(e.z),
+                                                                    __uint_as_float(e.w));
     }
 }
 
