@@ -124,6 +124,17 @@ int ddcn_deform_conv_backward_f32(const float *x, const float *weight, const flo
 int ddcn_modulated_deform_conv_forward_f32(const float *x, const float *weight, const float *bias,
                                            const float *offset, const float *mask, float *out, void *workspace,
                                            size_t workspace_bytes, const ddcn_geom *g, void *stream);
+/* No counterpart in the reference: the same forward (mask == NULL: the non-modulated op, bias may be NULL) for callers
+ * that CANNOT ALLOCATE -- code under HIP graph capture, tight serving loops, harnesses that forbid hipMalloc -- and so
+ * cannot bring a workspace either.  It calls no hipMalloc / hipFree / allocating routine: the columns live in a
+ * file-scope device array of DDCN_STATIC_SCRATCH_BYTES that every GPU the library runs on holds until the process
+ * ends.  Limit: ddcn_workspace_bytes(g) <= DDCN_STATIC_SCRATCH_BYTES, else DDCN_ERR_UNSUPPORTED (nothing is launched).
+ * All calls on one GPU share that GPU's array: calls that overlap on one GPU (other streams / threads) race. */
+#define DDCN_STATIC_SCRATCH_BYTES (64u << 20)
+size_t ddcn_static_scratch_bytes(void);
+int ddcn_modulated_deform_conv_forward_static_f32(const float *x, const float *weight, const float *bias,
+                                                  const float *offset, const float *mask, float *out,
+                                                  const ddcn_geom *g, void *stream);
 /* replaces modulated_deform_conv_cuda_backward (H:451-565) */
 int ddcn_modulated_deform_conv_backward_f32(const float *x, const float *weight, const float *offset,
                                             const float *mask, const float *grad_out, float *gx, float *goff,

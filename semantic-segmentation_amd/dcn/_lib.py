@@ -53,6 +53,8 @@ PROTOTYPES = {
     "ddcn_deform_conv_direct_forward_f32": [_P, _P, _P, _P, _P, ctypes.c_int, _P, _SZ, _G, _P],
     "ddcn_deform_conv_backward_f32": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _SZ, _G, _P],
     "ddcn_modulated_deform_conv_forward_f32": [_P, _P, _P, _P, _P, _P, _P, _SZ, _G, _P],
+    "ddcn_static_scratch_bytes": [],
+    "ddcn_modulated_deform_conv_forward_static_f32": [_P, _P, _P, _P, _P, _P, _G, _P],
     "ddcn_modulated_deform_conv_backward_f32": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _SZ, _G, _P],
     "ddcn_deform_conv_backward_saved_f32": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _SZ, _G, _P],
     "ddcn_modulated_deform_conv_backward_saved_f32": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _SZ, _G, _P],
@@ -82,6 +84,7 @@ _RESTYPES = {
     "ddcn_last_error": ctypes.c_char_p,
     "ddcn_col_ld": _SZ,
     "ddcn_workspace_bytes": _SZ,
+    "ddcn_static_scratch_bytes": _SZ,
     "ddcn_workspace_bytes_bf16": _SZ,
     "ddcn_workspace_bytes_f64": _SZ,
 }
