@@ -16,6 +16,10 @@ JSON line also carries op TFLOP/s and a roofline entry per kernel (measured live
 launch stream).  With --gpus N every rank runs the same per-GPU batch (weak scaling, images partitioned over
 ranks) and all-reduces grad_weight (SUM, then /world) as the reference's data-parallel training does
 (detseg/core/utils/dist_utils.py:22-28).
+
+Launch: `python bench.py --gpus N` starts its N ranks itself (one process per GPU, RCCL) BEFORE anything touches the
+GPU in the parent (semantic-segmentation_amd/launch.py, the counterpart of tools/dist_train.sh:8-9); under torchrun
+(WORLD_SIZE set) it is one rank of that job.  `--workload r101 --gpus N [--syncbn]` is BASELINE configs[3].
 """
 import argparse
 import ctypes
@@ -30,6 +34,17 @@ import torch.distributed as dist
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+
+
+def _load_launch():
+    """semantic-segmentation_amd/launch.py by path: the parent of an N-rank job must not import the package (that
+    would load the HIP library) before it has started its ranks."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("ddcn_launch", os.path.join(ROOT, "semantic-segmentation_amd",
+                                                                              "launch.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
 
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 MFMA_F32_PEAK_TF = 157.3   # MI355X_MICROARCH.md: FP32 matrix 157.3 TFLOP/s
@@ -106,13 +121,10 @@ def kernel_rooflines(w, tensors, iters):
         ("gemm_gweight", "mfma", a["f_gemm"] * N,
          lambda: _lib.check(L.ddcn_gemm_gweight_f32(p(gout), p(col), p(gw), g, s))),
     ]
-    # HBM bytes per launch from the PMC passes committed under profiles/ (rocprofv3 cannot run inside this process);
-    # they belong to the default workload only
-    traffic = {}
-    tf = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01j_hbm_traffic.json")
-    if os.path.exists(tf) and (w["N"], w["C"], w["Co"], w["H"], w["W"], w["dil"]) == (2, 512, 512, 97, 97, 4):
-        with open(tf) as fh:
-            traffic = {k: v["traffic_bytes"] for k, v in json.load(fh)["kernels"].items()}
+    # HBM bytes per launch come from the rocprofv3 --pmc passes committed under profiles/ (counters cannot be read from
+    # inside this process).  The file records the commit and a digest of csrc/ at collection time: when the kernels'
+    # sources have changed since, the figure is stale and is dropped (traffic = null) instead of being reported.
+    traffic, traffic_src = committed_traffic(w)
     res = []
     for name, bound, work, fn in stages:
         ms = time_stage(fn, iters)
@@ -121,32 +133,108 @@ def kernel_rooflines(w, tensors, iters):
         else:
             ach, peak, unit = work / ms / 1e9, MFMA_F32_PEAK_TF, "TFLOP/s"
         res.append(dict(kernel=name, bound=bound, ms=round(ms, 4), achieved=round(ach, 2), peak=peak, unit=unit,
-                        frac=round(ach / peak, 4), traffic=traffic.get(name)))
-    return res
+                        frac=round(ach / peak, 4), traffic=traffic.get(name), work=work))
+    return res, traffic_src
 
 
-def cpu_baseline(w, threads):
-    """The CPU oracle (a port of the reference algorithm; the reference has no CPU path) on ONE image of the
-    same layer, fwd+bwd, fp32, timed on this host."""
+def csrc_digest():
+    """sha256 over the kernel sources (csrc/*.hip, *.h and the public header), in name order."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    csrc = os.path.join(ROOT, "semantic-segmentation_amd", "csrc")
+    files = sorted(glob.glob(os.path.join(csrc, "*.hip")) + glob.glob(os.path.join(csrc, "*.h")))
+    files.append(os.path.join(ROOT, "include", "ddcn_hip.h"))
+    for f in files:
+        h.update(os.path.basename(f).encode())
+        with open(f, "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()
+
+
+def committed_traffic(w):
+    """({kernel: HBM bytes per launch}, provenance dict) from the newest profiles/*_hbm_traffic.json that belongs to
+    this workload AND to the kernel sources in the tree; ({}, reason) otherwise."""
+    import glob
+    if (w["N"], w["C"], w["Co"], w["H"], w["W"], w["dil"]) != (2, 512, 512, 97, 97, 4):
+        return {}, {"file": None, "why": "PMC passes are recorded for the default workload only"}
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_hbm_traffic.json")))
+    if not files:
+        return {}, {"file": None, "why": "no committed PMC file"}
+    with open(files[-1]) as fh:
+        rec = json.load(fh)
+    src = {"file": os.path.relpath(files[-1], ROOT), "commit": rec.get("commit"), "csrc_sha256": rec.get("csrc_sha256")}
+    if rec.get("csrc_sha256") != csrc_digest():
+        src["why"] = "stale: csrc/ changed since the counters were collected; figure dropped"
+        return {}, src
+    return {k: v["traffic_bytes"] for k, v in rec["kernels"].items()}, src
+
+
+def host_cpu_model():
+    try:
+        with open("/proc/cpuinfo") as fh:
+            for line in fh:
+                if line.lower().startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown CPU"
+
+
+def cpu_baseline(w):
+    """The reference algorithm on the host cores, whole workload (all N images), fwd+bwd, fp32: the C
+    oracle's OpenMP gather / scatter stages (oracle/ddcn_ref_impl.inc, a port of the CUDA kernels; the reference has
+    no CPU path) and torch.mm (the host BLAS) for G1-G3, composed per image in the reference's order
+    (deform_conv_cuda.cpp:419-448 forward, :497-561 backward).  Threads = the process's CPU share: OMP_NUM_THREADS when
+    the environment sets one (16 on the 1-GPU box, whose os.cpu_count() shows the whole machine), else every core."""
     from oracle import ddcn_oracle as orc
     import numpy as np
+    host = os.cpu_count() or 1
+    threads = max(1, min(host, int(os.environ.get("OMP_NUM_THREADS", host))))
     orc.set_threads(threads)
+    torch.set_num_threads(threads)
     rng = np.random.default_rng(0)
-    C, H, W = w["C"], w["H"], w["W"]
-    x = rng.standard_normal((1, C, H, W)).astype(np.float32)
-    weight = (rng.uniform(-1, 1, (w["Co"], C, 3, 3)) / np.sqrt(C * 9)).astype(np.float32)
-    offset = (rng.standard_normal((1, 18, H, W)) * 2).astype(np.float32)
-    mask = (1 / (1 + np.exp(-rng.standard_normal((1, 9, H, W))))).astype(np.float32)
-    gout = rng.standard_normal((1, w["Co"], H, W)).astype(np.float32)
-    kw = dict(stride=1, padding=w["pad"], dilation=w["dil"], groups=1, deformable_groups=1)
-    t0 = time.perf_counter()
-    orc.deform_forward(x, offset, mask, weight, None, **kw)
-    orc.deform_backward(x, offset, mask, weight, gout, False, **kw)
-    dt = time.perf_counter() - t0
+    N, C, Co, H, W = w["N"], w["C"], w["Co"], w["H"], w["W"]
+    x = rng.standard_normal((N, C, H, W)).astype(np.float32)
+    weight = (rng.uniform(-1, 1, (Co, C, 3, 3)) / np.sqrt(C * 9)).astype(np.float32)
+    offset = (rng.standard_normal((N, 18, H, W)) * w.get("offstd", 2)).astype(np.float32)
+    mask = (1 / (1 + np.exp(-rng.standard_normal((N, 9, H, W))))).astype(np.float32)
+    gout = rng.standard_normal((N, Co, H, W)).astype(np.float32)
+    geo = (3, 3, 1, w["pad"], w["dil"], w["dg"])
+    wm = torch.from_numpy(weight.reshape(Co, C * 9))
+    P = H * W
+
+    def step():
+        out = np.empty((N, Co, P), dtype=np.float32)
+        gx = np.empty_like(x)
+        goff = np.empty_like(offset)
+        gmask = np.empty_like(mask)
+        gw = torch.zeros(Co, C * 9)
+        for n in range(N):                                   # forward, per image as the reference loops
+            col = orc.im2col(x[n], offset[n], mask[n], *geo)
+            torch.mm(wm, torch.from_numpy(col), out=torch.from_numpy(out[n]))
+        for n in range(N):                                   # backward
+            go = torch.from_numpy(gout[n].reshape(Co, P))
+            gcol = torch.mm(wm.t(), go).numpy()                                       # G2
+            goff[n], gmask[n] = orc.col2im_coord(gcol, x[n], offset[n], mask[n], *geo)
+            gx[n] = orc.col2im(gcol, offset[n], mask[n], C, H, W, *geo)
+            col = orc.im2col(x[n], offset[n], mask[n], *geo)                          # recomputed, as the reference does
+            gw.addmm_(go, torch.from_numpy(col).t())                                  # G3
+        return out
+
+    step()                       # warm-up: page faults, BLAS thread pools
+    times = []
+    for _ in range(2):
+        t0 = time.perf_counter()
+        step()
+        times.append(time.perf_counter() - t0)
+    dt = min(times)
     a = alg_numbers(w)
-    return dict(value=round(a["b_total"] / dt / 1e9, 4), unit="GB/s", cores=threads, kind="port",
-                sample="1 image of the workload layer, fwd+bwd, fp32 C oracle (OpenMP), %.2f s" % dt,
-                tflops=round(a["f_total"] / dt / 1e12, 4))
+    return dict(value=round(a["b_total"] * N / dt / 1e9, 4), unit="GB/s", cores=threads, kind="port",
+                sample="the whole workload (N=%d images of the layer), fwd+bwd, fp32: C oracle gather/scatter (OpenMP) + "
+                       "torch.mm for G1-G3; best of 2 passes after a warm-up, %.2f s per pass; host: %s, os.cpu_count()=%d, "
+                       "threads used=%d" % (N, dt, host_cpu_model(), host, threads),
+                tflops=round(a["f_total"] * N / dt / 1e12, 4))
 
 
 MODEL_WORKLOADS = {
@@ -164,7 +252,11 @@ def model_workload(args, world, rank, dev):
     all-reduce over RCCL when world > 1, SGD(momentum, wd) update with the poly schedule."""
     callers = importlib.import_module("semantic-segmentation_amd.callers")
     cfg = MODEL_WORKLOADS[args.workload]
+    cfg = dict(cfg)
     n = args.batch if args.batch != 2 else cfg["batch"]     # --batch overrides the config's images per GPU
+    if args.hw:
+        cfg["h"], cfg["w"] = args.hw
+        cfg["name"] += " [input size overridden to %dx%d: a rehearsal, not the BASELINE workload]" % tuple(args.hw)
     torch.manual_seed(0)                                    # same initial weights on every rank
     backbone = callers.ResNet(cfg["depth"], strides=(1, 2, 1, 1), dilations=(1, 1, 2, 4),
                               dcn=dict(dcn_type="depthdeform"), stage_with_dcn=(False, True, True, True),
@@ -203,10 +295,13 @@ def model_workload(args, world, rank, dev):
         tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
+    devices = job_devices(dev, world)
+    grad_bytes = sum(p.numel() * p.element_size() for p in model.parameters() if p.requires_grad)
+    probe = allreduce_probe(dev, world, grad_bytes, iters=5) if world > 1 else None
     if rank == 0:
         print(json.dumps({
             "metric": "train images/sec", "value": round(n * world * args.steps / dt, 3), "unit": "images/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "n_gpus": dist.get_world_size() if world > 1 else 1, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": cfg["name"] + ", %d images/GPU, fwd+bwd+SGD step, random init" % n,
@@ -218,6 +313,10 @@ def model_workload(args, world, rank, dev):
                                                                "32 MiB buckets, overlapped with backward")},
             "final_loss": round(float(loss), 4),
             "peak_mem_GB": round(torch.cuda.max_memory_allocated() / 2 ** 30, 2),
+            "devices": devices,
+            "allreduce": None if probe is None else {
+                "gradient": probe, "backend": "nccl (RCCL)" if args.backend == "nccl" else "gloo (rehearsal)",
+                "distinct_devices": len({tuple(d[1:]) for d in devices})},
         }), flush=True)
 
 
@@ -275,7 +374,7 @@ def inference_workload(args, world, rank, dev):
         n_dcn = sum(1 for m in model.modules() if type(m).__name__ == "ModulatedDeformConvPack")
         print(json.dumps({
             "metric": "inference images/sec", "value": round(n * world * args.steps / dt, 3), "unit": "images/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "n_gpus": dist.get_world_size() if world > 1 else 1, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
             "config": {"workload": "BASELINE configs[4]: ResNet101 with modulated DDCN (dg=4) in all %d bottlenecks + "
@@ -285,6 +384,38 @@ def inference_workload(args, world, rank, dev):
             "output_shape": list(out.shape), "finite": bool(torch.isfinite(out.float()).all()),
             "peak_mem_GB": round(torch.cuda.max_memory_allocated() / 2 ** 30, 2),
         }), flush=True)
+
+
+def allreduce_probe(dev, world, nbytes, iters=10):
+    """One fp32 all-reduce (SUM) of `nbytes` over the job's ranks, alone: ms per call (max over ranks is implied by
+    the collective) and bus bandwidth 2(N-1)/N * bytes / time, the figure comparable to the 7 x ~153 GB/s xGMI links."""
+    buf = torch.ones(nbytes // 4, device=dev)
+    for _ in range(2):
+        dist.all_reduce(buf)
+    torch.cuda.synchronize()
+    dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        dist.all_reduce(buf)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / iters
+    t = torch.tensor([dt], device=dev, dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dt = float(t.item())
+    return dict(bytes=nbytes, ms=round(dt * 1e3, 4), bus_GBps=round(2 * (world - 1) / world * nbytes / dt / 1e9, 2))
+
+
+def job_devices(dev, world):
+    """What each rank really runs on: [rank, local device index, device name, uuid or PCI bus id], gathered on every rank."""
+    props = torch.cuda.get_device_properties(dev)
+    ident = str(getattr(props, "uuid", "")) or str(getattr(props, "pci_bus_id", ""))
+    mine = [dist.get_rank() if world > 1 else 0, dev.index, props.name, ident]
+    if world == 1:
+        return [mine]
+    out = [None] * world
+    dist.all_gather_object(out, mine)
+    return out
 
 
 def main():
@@ -306,19 +437,47 @@ def main():
     ap.add_argument("--sync-allreduce", action="store_true",
                     help="model workloads, N > 1: all-reduce after backward (the reference's order) instead of under it")
     ap.add_argument("--no-graph", action="store_true", help="cfg5: launch eagerly instead of replaying a HIP graph")
+    ap.add_argument("--backend", choices=("nccl", "gloo"), default="nccl",
+                    help="N > 1: 'nccl' = RCCL over xGMI, one GPU per rank (the measured configuration); 'gloo' = a "
+                         "rehearsal of the N-rank code path on fewer GPUs than ranks (rank r uses GPU r %% #GPUs and the "
+                         "collectives go through host memory) -- its numbers are not a scaling measurement")
+    ap.add_argument("--hw", type=int, nargs=2, metavar=("H", "W"), default=None,
+                    help="model workloads: override the input size (rehearsals and tests; the reported workload says so)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     args = ap.parse_args()
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if os.environ.get("DDCN_BENCH_WATCHDOG"):     # debugging aid: dump every thread's stack after N seconds
+        import faulthandler
+        faulthandler.dump_traceback_later(int(os.environ["DDCN_BENCH_WATCHDOG"]), exit=False)
+    launch = _load_launch()
+    if not launch.under_launcher():
+        if args.gpus > 1:
+            # The N ranks are started here, by a parent that has made no GPU call (device_count() does not initialise
+            # the GPU on this image); each is a fresh interpreter, never a re-exec of a process that touched the GPU.
+            have = torch.cuda.device_count()
+            if have < (args.gpus if args.backend == "nccl" else 1):
+                raise SystemExit("bench.py --gpus %d: only %d GPU(s) visible" % (args.gpus, have))
+            sys.exit(launch.spawn_ranks(args.gpus, sys.argv[1:], script=os.path.abspath(__file__)))
+        world, rank, local_rank = 1, 0, 0
+    else:
+        world = int(os.environ["WORLD_SIZE"])
+        rank = int(os.environ["RANK"])
+        local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        if rank == 0 and args.gpus != world:
+            print("bench: --gpus %d but the launcher started %d ranks; running %d" % (args.gpus, world, world),
+                  file=sys.stderr)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    if world > 1:
-        dist.init_process_group("nccl", device_id=dev)   # "nccl" is RCCL on ROCm
+    if world > 1 and args.backend == "nccl":
+        rank, world, dev = launch.init_dist("pytorch", backend="nccl")   # "nccl" is RCCL on ROCm
+    else:
+        if world > 1:
+            rank, world, _ = launch.init_dist("pytorch", backend="gloo")
+        dev = torch.device("cuda", local_rank % torch.cuda.device_count())
+        torch.cuda.set_device(dev)
     pkg = importlib.import_module("semantic-segmentation_amd")
     dist_utils = importlib.import_module("semantic-segmentation_amd.dist_utils")
 
@@ -366,11 +525,12 @@ def main():
 
     a = alg_numbers(w)
     images = w["N"] * world * args.steps
+    devices = job_devices(dev, world)
     line = {
         "metric": "DDCN op fwd+bwd GB/s",
         "value": round(a["b_total"] * images / dt / 1e9, 2),
         "unit": "GB/s",
-        "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "n_gpus": dist.get_world_size() if world > 1 else 1, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(dt / args.steps * 1e3, 4),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
@@ -381,16 +541,32 @@ def main():
                    "alg_bytes_per_image": a["b_total"], "alg_flops_per_image": a["f_total"]},
         "op_tflops": round(a["f_total"] * images / dt / 1e12, 2),
         "images_per_s": round(images / dt, 2),
+        "devices": devices,
     }
+    if world > 1:
+        # the layer's own exchange (grad_weight) and, for scale, the gradient of BASELINE configs[3]'s model
+        # (DDCN-ResNet101 + DANet head: ~69 M fp32 parameters = 276 MB in one step)
+        line["allreduce"] = {"grad_weight": allreduce_probe(dev, world, weight.numel() * 4),
+                             "configs3_gradient": allreduce_probe(dev, world, 69_000_000 * 4, iters=5),
+                             "backend": "nccl (RCCL)", "distinct_devices": len({tuple(d[1:]) for d in devices})}
     if rank == 0 and world == 1 and not args.no_kernel_timing:
-        ks = kernel_rooflines(w, [t.detach() for t in (x, weight, offset, mask)] + [gout], max(5, args.steps // 2))
+        ks, traffic_src = kernel_rooflines(w, [t.detach() for t in (x, weight, offset, mask)] + [gout],
+                                           max(5, args.steps // 2))
         dom = max((k for k in ks if k["bound"] == "mfma"), key=lambda k: k["ms"])
         line["roofline"] = {k: dom[k] for k in ("bound", "achieved", "peak", "unit", "frac", "traffic")}
         line["roofline"]["kernel"] = dom["kernel"]
+        line["roofline"]["traffic_source"] = traffic_src
+        # the bytes the kernels that really ran moved, over their own time: im2col runs ONCE per step here (the
+        # columns are kept for backward) and the scatter is one fused pass, while `value` prices the reference's
+        # four passes (2 x im2col + col2im + col2im_coord) against the whole step
+        gath = [k for k in ks if k["bound"] == "hbm"]
+        line["gather_GBps_executed"] = round(sum(k["work"] for k in gath) / sum(k["ms"] for k in gath) / 1e6, 1)
+        line["gather_ms_executed"] = round(sum(k["ms"] for k in gath), 4)
+        for k in ks:
+            del k["work"]
         line["roofline_kernels"] = ks
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        threads = min(16, os.cpu_count() or 1)
-        line["cpu_baseline"] = cpu_baseline(w, threads)
+        line["cpu_baseline"] = cpu_baseline(w)
     if rank == 0:
         print(json.dumps(line), flush=True)
     if world > 1:

@@ -57,10 +57,16 @@ class OverlappedGradReducer:
     The reference reduces after backward has finished (`_allreduce_coalesced`, dist_utils.py:9-28, called from its
     optimizer hook).  Here every parameter gets a post-accumulate-grad hook; parameters are assigned to buckets of
     `bucket_size_mb` in REVERSE registration order (roughly the order backward produces their gradients); when the
-    last gradient of a bucket arrives the bucket is flattened and its all-reduce is issued asynchronously (RCCL
-    runs it on its own stream, over xGMI, under the rest of backward).  `finish()` waits, divides by the world
-    size and copies the results back into the .grad tensors; call it before optimizer.step().  A parameter that
-    receives no gradient in an iteration is reduced as zeros, so every rank issues the same collectives.
+    last gradient of a bucket arrives the bucket becomes ready, and ready buckets are flattened and all-reduced
+    asynchronously (RCCL runs them on its own stream, over xGMI, under the rest of backward) STRICTLY IN BUCKET
+    ORDER: bucket i is issued only after buckets 0..i-1, and `finish()` issues whatever is left, also in order.
+    Every rank therefore issues the same collectives in the same order whatever order its hooks fire in -- also when
+    a rank leaves some parameter without a gradient (it is reduced as zeros).  `finish()` waits, divides by the
+    world size and copies the results back into the .grad tensors; call it before optimizer.step().
+
+    One backward per finish().  For gradient accumulation run the earlier backward passes inside `no_sync()`
+    (hooks are ignored, gradients only accumulate) and the last one outside; a hook that fires for a bucket that
+    was already issued raises instead of silently reducing a stale gradient.
     """
 
     def __init__(self, model_or_params, bucket_size_mb=32, process_group=None):
@@ -80,28 +86,58 @@ class OverlappedGradReducer:
         if cur:
             self.buckets.append(cur)
         self._bucket_of = {id(p): i for i, b in enumerate(self.buckets) for p in b}
-        self._pending = [len(b) for b in self.buckets]
-        self._inflight = {}
+        self._sync = True
+        self._reset()
+        self.issued_order = []      # bucket indices in the order their all-reduce was issued (last iteration; tests)
         self._handles = [p.register_post_accumulate_grad_hook(self._on_grad) for p in self.params]
 
-    def _launch(self, i):
-        bucket = self.buckets[i]
+    def _reset(self):
+        self._pending = [len(b) for b in self.buckets]
+        self._next = 0              # buckets below this index have been issued
+        self._inflight = []         # (flat, work) of bucket i at position i
+
+    def _launch_next(self):
+        bucket = self.buckets[self._next]
         flat = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1) for p in bucket])
-        self._inflight[i] = (flat, dist.all_reduce(flat, group=self.group, async_op=True))
+        self._inflight.append((flat, dist.all_reduce(flat, group=self.group, async_op=True)))
+        self.issued_order.append(self._next)
+        self._next += 1
 
     def _on_grad(self, p):
+        if not self._sync:
+            return
         i = self._bucket_of[id(p)]
+        if i < self._next or self._pending[i] <= 0:
+            raise RuntimeError(
+                "OverlappedGradReducer: a gradient arrived for a bucket that was already reduced in this iteration "
+                "(a second backward before finish()); wrap all but the last backward in reducer.no_sync()")
+        if self._next == 0 and not self._inflight:
+            self.issued_order = []
         self._pending[i] -= 1
-        if self._pending[i] == 0:
-            self._launch(i)
+        while self._next < len(self.buckets) and self._pending[self._next] == 0:
+            self._launch_next()
+
+    def no_sync(self):
+        """Context manager: backward passes inside only accumulate into .grad (no all-reduce is issued)."""
+        reducer = self
+
+        class _NoSync:
+            def __enter__(self):
+                reducer._sync = False
+
+            def __exit__(self, *exc):
+                reducer._sync = True
+                return False
+        return _NoSync()
 
     def finish(self):
-        """Wait for every bucket, divide by the world size, write back; buckets whose hooks did not all fire
-        (unused parameters) are reduced now."""
-        for i in range(len(self.buckets)):
-            if i not in self._inflight:
-                self._launch(i)
-        for i, (flat, work) in sorted(self._inflight.items()):
+        """Issue the buckets that are still missing (parameters without a gradient on this rank) in order, wait for
+        every bucket, divide by the world size and write the means back."""
+        if self._next == 0 and not self._inflight:
+            self.issued_order = []
+        while self._next < len(self.buckets):
+            self._launch_next()
+        for i, (flat, work) in enumerate(self._inflight):
             work.wait()
             flat.div_(self.world)
             o = 0
@@ -112,8 +148,7 @@ class OverlappedGradReducer:
                 else:
                     p.grad.copy_(flat[o:o + n].view_as(p))
                 o += n
-        self._inflight.clear()
-        self._pending = [len(b) for b in self.buckets]
+        self._reset()
 
     def remove(self):
         for h in self._handles:

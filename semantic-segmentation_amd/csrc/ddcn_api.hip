@@ -52,9 +52,10 @@ static int check_geom(const ddcn_geom *g)
     if (t.Ho != g->Ho || t.Wo != g->Wo)
         return fail(DDCN_ERR_SHAPE, "invalid spatial size of offset/output, expected height: %d width: %d, but got height: %d width: %d",
                     t.Ho, t.Wo, g->Ho, g->Wo);
-    const Dims d = dims_of(*g);
-    // 32-bit index budget of the kernels (per-image planes and column rows)
-    if ((long)g->H * g->W >= (1L << 31) || (long)d.P >= (1L << 31) - 1024 || (long)d.Ktot >= (1L << 31))
+    // 32-bit index budget of the kernels (per-image planes and column rows), formed in 64 bits: the int products
+    // inside dims_of() have already wrapped for the sizes this test is there to reject
+    const long P = (long)t.Ho * t.Wo, Ktot = (long)g->C * g->kh * g->kw;
+    if ((long)g->H * g->W >= (1L << 31) || P >= (1L << 31) - 1024 || Ktot >= (1L << 31))
         return fail(DDCN_ERR_UNSUPPORTED, "tensor plane exceeds 2^31 elements");
     return DDCN_OK;
 }
@@ -116,11 +117,18 @@ int ddcn_infer_output(ddcn_geom *g)
 
 int ddcn_check_geom(const ddcn_geom *g) { return check_geom(g); }
 
-size_t ddcn_col_ld(const ddcn_geom *g) { return g ? (size_t)dims_of(*g).ld : 0; }
+// the size queries never throw and never divide by an unvalidated group count: 0 for a geometry dims_of() cannot take
+static bool sizes_defined(const ddcn_geom *g)
+{
+    return g && g->groups > 0 && g->dg > 0 && g->N > 0 && g->C > 0 && g->kh > 0 && g->kw > 0 && g->Ho > 0 && g->Wo > 0 &&
+           (long)g->Ho * g->Wo < (1L << 31) - 1024 && (long)g->C * g->kh * g->kw < (1L << 31);
+}
+
+size_t ddcn_col_ld(const ddcn_geom *g) { return sizes_defined(g) ? (size_t)dims_of(*g).ld : 0; }
 
 size_t ddcn_workspace_bytes(const ddcn_geom *g)
 {
-    if (!g) return 0;
+    if (!sizes_defined(g)) return 0;
     const Dims d = dims_of(*g);
     return sizeof(float) * (size_t)g->N * (size_t)d.Ktot * (size_t)d.ld;
 }

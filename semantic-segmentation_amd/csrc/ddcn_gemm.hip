@@ -391,10 +391,10 @@ static int launch(GemmArgs &a, int nz0, hipStream_t stream, const char *what)
     // per-lane byte offsets are 32 bit and span one tile of rows: 128 rows * ld * 4 bytes must stay below 2^30
     if (a.lda >= (1L << 21) || a.ldb >= (1L << 21) || a.ldc >= (1L << 21))
         return fail(DDCN_ERR_UNSUPPORTED, "%s: leading dimension beyond 2^21 elements", what);
-    // > 64 KiB of dynamic LDS needs the opt-in; set per call (cheap, and correct for every device of the process)
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_f32_mfma<A_KC, B_KC, ATOMIC>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-    if (e != hipSuccess) return fail(DDCN_ERR_LAUNCH, "%s: hipFuncSetAttribute: %s", what, hipGetErrorString(e));
+    // > 64 KiB of dynamic LDS needs the opt-in: raised once per device to this instantiation's (constant) size
+    static std::atomic<uint64_t> raised{0};
+    if (!raise_lds_limit(reinterpret_cast<const void *>(&gemm_f32_mfma<A_KC, B_KC, ATOMIC>), (int)smem, raised))
+        return fail(DDCN_ERR_LAUNCH, "%s: cannot raise the dynamic LDS limit to %zu bytes", what, smem);
     a.tiles_m = (a.M + BM - 1) / BM;
     const long tiles_n = (a.N + BN - 1) / BN;
     const long nz = (long)nz0 * a.nz1 * a.ksplit;

@@ -388,16 +388,29 @@ static int run_tile(const Im2colTileArgs &a, bool mod, hipStream_t stream, const
         else                                                                                                \
             hipLaunchKernelGGL((im2col_tile_kernel<false, NC, SKW>), grid, dim3(IT), smem, stream, a);      \
     } while (0)
-    hipError_t e = hipSuccess;
-    if (smem > 64 * 1024) {
-        // > 64 KiB of dynamic LDS needs the opt-in (set for every instantiation that can be launched below)
-        const void *fns[] = {(const void *)&im2col_tile_kernel<true, 10, SKW>, (const void *)&im2col_tile_kernel<false, 10, SKW>,
-                             (const void *)&im2col_tile_kernel<true, 12, SKW>, (const void *)&im2col_tile_kernel<false, 12, SKW>,
+    // > 64 KiB of dynamic LDS needs the opt-in: every instantiation is raised once per device to the largest patch the
+    // planner admits (MAXCELLS * IT cells, double buffered, + the direct mode's weights), not per call
+    constexpr int LDS_MAX = 2 * MAXCELLS * IT * CC * (int)sizeof(float) + CC * 9 * SKMAX * (int)sizeof(float);
+    if (smem > (size_t)LDS_MAX) return fail(DDCN_ERR_UNSUPPORTED, "%s: patch of %zu bytes exceeds the LDS plan", what, smem);
+    {
+        static std::atomic<uint64_t> raised{0};
+        const void *fns[] = {(const void *)&im2col_tile_kernel<true, 2, SKW>, (const void *)&im2col_tile_kernel<false, 2, SKW>,
+                             (const void *)&im2col_tile_kernel<true, 4, SKW>, (const void *)&im2col_tile_kernel<false, 4, SKW>,
+                             (const void *)&im2col_tile_kernel<true, 6, SKW>, (const void *)&im2col_tile_kernel<false, 6, SKW>,
                              (const void *)&im2col_tile_kernel<true, 8, SKW>, (const void *)&im2col_tile_kernel<false, 8, SKW>,
-                             (const void *)&im2col_tile_kernel<true, 6, SKW>, (const void *)&im2col_tile_kernel<false, 6, SKW>};
-        for (const void *fn : fns)
-            if (e == hipSuccess) e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-        if (e != hipSuccess) return fail(DDCN_ERR_LAUNCH, "%s: hipFuncSetAttribute: %s", what, hipGetErrorString(e));
+                             (const void *)&im2col_tile_kernel<true, 10, SKW>, (const void *)&im2col_tile_kernel<false, 10, SKW>,
+                             (const void *)&im2col_tile_kernel<true, 12, SKW>, (const void *)&im2col_tile_kernel<false, 12, SKW>};
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess) return fail(DDCN_ERR_NO_DEVICE, "%s: hipGetDevice failed", what);
+        const uint64_t bit = dev < 64 ? (1ull << dev) : 0;
+        if (!bit || !(raised.load(std::memory_order_acquire) & bit)) {
+            for (const void *fn : fns) {
+                std::atomic<uint64_t> scratch_flag{0};
+                if (!raise_lds_limit(fn, LDS_MAX, scratch_flag))
+                    return fail(DDCN_ERR_LAUNCH, "%s: cannot raise the dynamic LDS limit to %d bytes", what, LDS_MAX);
+            }
+            raised.fetch_or(bit, std::memory_order_release);
+        }
     }
     if (ncell <= 2) DDCN_IM2COL_LAUNCH(2);
     else if (ncell <= 4) DDCN_IM2COL_LAUNCH(4);

@@ -241,8 +241,12 @@ int launch_col2im_coord_tiled(const float *gcol, const float *x, const float *of
     const size_t smem = (size_t)(3 * d.K2 * TT + 2 * a.CC * a.RS) * sizeof(float);
     const void *fn = mask ? reinterpret_cast<const void *>(&col2im_coord_tile_kernel<true>)
                           : reinterpret_cast<const void *>(&col2im_coord_tile_kernel<false>);
-    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-    if (e != hipSuccess) return fail(DDCN_ERR_LAUNCH, "col2im_coord_tile: hipFuncSetAttribute: %s", hipGetErrorString(e));
+    // raised once per device to the planner's cap (plan_tiles never exceeds it), not per call to this call's size
+    static const int env_kb = getenv("DDCN_TILE_LDS_KB") ? atoi(getenv("DDCN_TILE_LDS_KB")) : 0;
+    const int lds_limit = (env_kb > 0 ? env_kb : 76) * 1024;
+    static std::atomic<uint64_t> raised_mod{0}, raised_plain{0};
+    if ((int)smem > lds_limit || !raise_lds_limit(fn, lds_limit, mask ? raised_mod : raised_plain))
+        return fail(DDCN_ERR_LAUNCH, "col2im_coord_tile: cannot raise the dynamic LDS limit to %d bytes", lds_limit);
     if (mask)
         hipLaunchKernelGGL((col2im_coord_tile_kernel<true>), grid, dim3(TT), smem, stream, a);
     else

@@ -30,6 +30,7 @@ constexpr int ST = 256;
 #endif
 constexpr int SMAXCELLS = 8;
 constexpr unsigned SOOB = 0x80000000u;
+constexpr int S9_LDS_MAX = 80 * 1024;   // planner's cap on the dynamic LDS of one workgroup (two per CU)
 
 struct Tile9Args {
     const float *gcol, *x, *offset, *mask;
@@ -434,7 +435,7 @@ int launch_col2im_coord_tile9(const float *gcol, const float *x, const float *of
     for (int M = env_m; M >= 0 && !ok; M -= 2) {
         const int RH = (TH - 1) * g.sh + 2 * g.dh + 2 + 2 * M;
         const int RW = (TW - 1) * g.sw + 2 * g.dw + 2 + 2 * M;
-        if (RH * RW <= SMAXCELLS * ST && (size_t)RH * RW * 12 * SC <= (size_t)(SC == 4 ? 80 : 40) * 1024) {
+        if (RH * RW <= SMAXCELLS * ST && (size_t)RH * RW * 12 * SC <= (size_t)(SC == 4 ? S9_LDS_MAX : S9_LDS_MAX / 2)) {
             a.M = M; a.RH = RH; a.RW = RW; a.RS = RH * RW;
             ok = true;
         }
@@ -456,12 +457,13 @@ int launch_col2im_coord_tile9(const float *gcol, const float *x, const float *of
     const bool fx = env_fx && atoi(env_fx) != 0 && SC == 4;
     const size_t smem = (size_t)a.RS * (fx ? 8 : 12) * SC;
     const int ncell = (a.RS + ST - 1) / ST;
-    hipError_t e = hipSuccess;
+    bool ok_lds = true;
+    // each instantiation's dynamic-LDS limit is raised once per device to the planner's cap (80 KiB), not per call
 #define DDCN_S9_LAUNCH2(MOD, NC, SCV, FXV)                                                                       \
     do {                                                                                                         \
-        e = hipFuncSetAttribute((const void *)&col2im_coord_tile9_kernel<MOD, NC, SCV, FXV>,                     \
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);                          \
-        if (e == hipSuccess)                                                                                     \
+        static std::atomic<uint64_t> raised{0};                                                                  \
+        ok_lds = raise_lds_limit((const void *)&col2im_coord_tile9_kernel<MOD, NC, SCV, FXV>, S9_LDS_MAX, raised); \
+        if (ok_lds)                                                                                              \
             hipLaunchKernelGGL((col2im_coord_tile9_kernel<MOD, NC, SCV, FXV>), grid, dim3(ST), smem, stream, a); \
     } while (0)
 #define DDCN_S9_LAUNCH(NC)                                                                                       \
@@ -479,7 +481,7 @@ int launch_col2im_coord_tile9(const float *gcol, const float *x, const float *of
     else DDCN_S9_LAUNCH(8);
 #undef DDCN_S9_LAUNCH2
 #undef DDCN_S9_LAUNCH
-    if (e != hipSuccess) return fail(DDCN_ERR_LAUNCH, "col2im_coord_tile9: hipFuncSetAttribute: %s", hipGetErrorString(e));
+    if (!ok_lds) return fail(DDCN_ERR_LAUNCH, "col2im_coord_tile9: cannot raise the dynamic LDS limit to %d bytes", S9_LDS_MAX);
     return check_launch("col2im_coord_tile9");
 }
 

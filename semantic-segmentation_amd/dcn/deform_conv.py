@@ -119,8 +119,7 @@ def _workspace(input, g, cd=torch.float32):
     return torch.empty(nbytes // 4, dtype=torch.float32, device=input.device), nbytes
 
 
-def _zeros_like_all(*tensors):
-    """Zero-filled gradients for all tensors from ONE flat buffer and one fill kernel (each view 16-byte aligned)."""
+def _zeros_flat(tensors):
     sizes = [(t.numel() + 3) // 4 * 4 for t in tensors]
     flat = torch.zeros(sum(sizes), dtype=tensors[0].dtype, device=tensors[0].device)
     out, o = [], 0
@@ -128,6 +127,14 @@ def _zeros_like_all(*tensors):
         out.append(flat[o:o + t.numel()].view(t.shape))
         o += n
     return out
+
+
+def _zeros_like_all(*tensors):
+    """Zero-filled gradients for all tensors (each view 16-byte aligned).  The activation-sized gradients (every
+    tensor but the last two: ..., weight, bias) share ONE flat buffer and one fill kernel; grad_weight and grad_bias
+    come from a small buffer of their own, because autograd keeps them alive as `param.grad` long after the
+    activation gradients are gone and a view would pin the whole activation-sized buffer with it."""
+    return _zeros_flat(tensors[:-2]) + _zeros_flat(tensors[-2:])
 
 
 def _expect_shape(name, t, shape):

@@ -67,6 +67,14 @@ class DeformRoIPoolingFunction(Function):
         ctx.pool_args = (spatial_scale, out_size, out_channels, bool(no_trans), group_size, part_size,
                          sample_per_part, trans_std)
         _check_dtype_cuda("data", data, data.dtype)
+        # rois / offset on the host (or on another GPU) would hand the kernel a pointer it cannot read: refuse them here
+        for name, t in (("rois", rois),) + ((() if no_trans else (("offset", offset),))):
+            if not t.is_cuda:
+                raise NotImplementedError
+            if t.device != data.device:
+                raise RuntimeError("ddcn: %s is on %s but data is on %s" % (name, t.device, data.device))
+            if not t.is_floating_point():
+                raise RuntimeError("ddcn: %s must be a floating-point tensor, got %s" % (name, t.dtype))
         ctx.dtype = data.dtype
         if not data.is_contiguous():  # deform_pool_cuda.cpp:39
             raise RuntimeError("input tensor has to be contiguous")
@@ -79,9 +87,10 @@ class DeformRoIPoolingFunction(Function):
         n = rois.shape[0]
         output = torch.empty((n, out_channels, out_size, out_size), dtype=cd, device=data.device)
         output_count = torch.empty_like(output)
-        _lib.check(_entry("ddcn_deform_psroi_pool_forward", cd)(
-            _lib.ptr(data32), _lib.ptr(rois32), _lib.ptr(offset32), _lib.ptr(output), _lib.ptr(output_count), g,
-            _lib.current_stream(data.device)))
+        with torch.cuda.device(data.device):
+            _lib.check(_entry("ddcn_deform_psroi_pool_forward", cd)(
+                _lib.ptr(data32), _lib.ptr(rois32), _lib.ptr(offset32), _lib.ptr(output), _lib.ptr(output_count), g,
+                _lib.current_stream(data.device)))
 
         if data.requires_grad or rois.requires_grad or offset.requires_grad:  # PP:52-53
             ctx.save_for_backward(data, rois, offset)
@@ -94,6 +103,8 @@ class DeformRoIPoolingFunction(Function):
         if not grad_output.is_cuda:
             raise NotImplementedError
         data, rois, offset = ctx.saved_tensors
+        if grad_output.device != data.device:
+            raise RuntimeError("ddcn: grad_output is on %s but data is on %s" % (grad_output.device, data.device))
         no_trans = ctx.pool_args[3]
         g = _roi_geom(data, rois, offset, *ctx.pool_args)
         cd = _cdtype(ctx.dtype)
@@ -105,10 +116,11 @@ class DeformRoIPoolingFunction(Function):
         # PP:66-68: both gradients start from zero, the kernel accumulates
         grad_input = torch.zeros(data.shape, dtype=cd, device=data.device)
         grad_offset = torch.zeros(offset.shape, dtype=cd, device=data.device)
-        _lib.check(_entry("ddcn_deform_psroi_pool_backward", cd)(
-            _lib.ptr(grad_out32), _lib.ptr(data32), _lib.ptr(rois32), _lib.ptr(offset32),
-            _lib.ptr(ctx.output_count), _lib.ptr(grad_input), None if no_trans else _lib.ptr(grad_offset), g,
-            _lib.current_stream(data.device)))
+        with torch.cuda.device(data.device):
+            _lib.check(_entry("ddcn_deform_psroi_pool_backward", cd)(
+                _lib.ptr(grad_out32), _lib.ptr(data32), _lib.ptr(rois32), _lib.ptr(offset32),
+                _lib.ptr(ctx.output_count), _lib.ptr(grad_input), None if no_trans else _lib.ptr(grad_offset), g,
+                _lib.current_stream(data.device)))
         if ctx.dtype != cd:
             grad_input, grad_offset = grad_input.to(ctx.dtype), grad_offset.to(ctx.dtype)
         # no gradient for rois (PP:67) nor for the eight scalars

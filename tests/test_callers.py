@@ -182,3 +182,96 @@ def test_world2_training_reproduces_single_process_loss_curve(overlapped):
     for a, b in zip(dp_params, list(single_model.parameters())[:3]):
         assert torch.allclose(torch.from_numpy(a), b.detach(), rtol=1e-3, atol=1e-5)
 
+
+
+# ------------------------------------------------------------------ OverlappedGradReducer: collective order, re-entry
+class _TwoBranch(torch.nn.Module):
+    def __init__(self):
+        super().__init__()
+        torch.manual_seed(5)
+        self.a = torch.nn.Linear(6, 6)
+        self.b = torch.nn.Linear(6, 6)
+        self.c = torch.nn.Linear(6, 3)
+
+    def forward(self, x, use_b):
+        h = self.a(x)
+        if use_b:
+            h = h + self.b(x)
+        return self.c(h)
+
+
+def _order_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    m = _TwoBranch()
+    # one parameter per bucket: hook-firing order == bucket-ready order, so an out-of-order issue would mismatch
+    red = callers.OverlappedGradReducer(m, bucket_size_mb=1e-6)
+    assert len(red.buckets) == 6
+    g = torch.Generator().manual_seed(7)
+    x = torch.randn(4, 6, generator=g)[2 * rank:2 * rank + 2]
+    m(x, use_b=(rank == 0)).square().sum().backward()      # rank 1 leaves branch b without a gradient
+    red.finish()
+    order = list(red.issued_order)
+    grads = {n: p.grad.clone() for n, p in m.named_parameters()}
+    # second iteration with gradient accumulation: first backward under no_sync, second one reduces the sum
+    for p in m.parameters():
+        p.grad = None
+    with red.no_sync():
+        m(x, use_b=True).sum().backward()
+    m(x, use_b=True).sum().backward()
+    red.finish()
+    acc = {n: p.grad.clone() for n, p in m.named_parameters()}
+    # third: a second backward WITHOUT no_sync must raise, not reduce stale data
+    for p in m.parameters():
+        p.grad = None
+    m(x, use_b=True).sum().backward()
+    raised = False
+    try:
+        m(x, use_b=True).sum().backward()
+    except RuntimeError as e:
+        raised = "no_sync" in str(e)
+    red.finish()
+    if rank == 0:
+        q.put((order, {k: v.numpy().copy() for k, v in grads.items()}, {k: v.numpy().copy() for k, v in acc.items()},
+               raised))
+    else:
+        q.put((order, None, None, raised))
+    dist.destroy_process_group()
+
+
+def test_overlapped_reducer_issues_buckets_in_order_with_rank_dependent_unused_parameters():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_order_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(r[0] == [0, 1, 2, 3, 4, 5] for r in res)          # same order on both ranks, whatever fired first
+    assert all(r[3] for r in res)                                  # re-entry detected on both ranks
+    grads, acc = next((r[1], r[2]) for r in res if r[1] is not None)
+    # expected: mean over the two ranks of the local gradients (a missing gradient counts as zero)
+    m = _TwoBranch()
+    g = torch.Generator().manual_seed(7)
+    xs = torch.randn(4, 6, generator=g)
+    exp = {n: torch.zeros_like(p) for n, p in m.named_parameters()}
+    for rank in range(2):
+        m.zero_grad(set_to_none=True)
+        m(xs[2 * rank:2 * rank + 2], use_b=(rank == 0)).square().sum().backward()
+        for n, p in m.named_parameters():
+            if p.grad is not None:
+                exp[n] += p.grad / 2
+    for n in exp:
+        assert torch.allclose(torch.from_numpy(grads[n]), exp[n], atol=1e-6), n
+    exp2 = {n: torch.zeros_like(p) for n, p in m.named_parameters()}
+    for rank in range(2):
+        m.zero_grad(set_to_none=True)
+        m(xs[2 * rank:2 * rank + 2], use_b=True).sum().backward()
+        m(xs[2 * rank:2 * rank + 2], use_b=True).sum().backward()
+        for n, p in m.named_parameters():
+            exp2[n] += p.grad / 2
+    for n in exp2:
+        assert torch.allclose(torch.from_numpy(acc[n]), exp2[n], atol=1e-6), n

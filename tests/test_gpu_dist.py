@@ -1,0 +1,57 @@
+"""The N-rank path on the GPU box: bench.py starts its own ranks.
+
+  * RCCL, world size 2: needs two GPUs (skipped on the 1-GPU box; the driver's multi-GPU tier runs it).
+  * the SyncBN variant of BASELINE configs[3] (configs/sunrgbd/danet_r101_depthdeform.py:13,20,26:
+    norm_cfg = SyncBN) likewise needs two GPUs: torch's SyncBatchNorm refuses CPU tensors, and two ranks sharing ONE
+    GPU over gloo (`bench.py --backend gloo`) stall inside SyncBatchNorm's all_gather after a few layers on this
+    stack (measured in round 2; plain gloo collectives on GPU tensors work), so no one-GPU rehearsal is collected.
+"""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+import torch
+
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+
+
+def _bench(*argv, timeout=600):
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + list(argv), env=env, capture_output=True,
+                       text=True, timeout=timeout)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout          # ONE JSON line, from rank 0
+    return json.loads(lines[0])
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs (RCCL refuses two ranks on one device)")
+def test_bench_gpus2_runs_two_ranks_on_rccl():
+    line = _bench("--gpus", "2", "--steps", "3", "--warmup", "1")
+    assert line["n_gpus"] == 2 and line["config"]["parallelism"] == "dp2"
+    assert line["allreduce"]["distinct_devices"] == 2 and len(line["devices"]) == 2
+    assert line["allreduce"]["configs3_gradient"]["bytes"] == 276_000_000
+    assert line["allreduce"]["configs3_gradient"]["bus_GBps"] > 0
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs (RCCL refuses two ranks on one device)")
+def test_bench_gpus2_syncbn_model_workload_on_rccl():
+    """The SyncBN variant of BASELINE configs[3] at a reduced input size: SyncBatchNorm's all_gather / all_reduce and
+    the bucketed, backward-overlapped gradient all-reduce, all over RCCL."""
+    line = _bench("--gpus", "2", "--workload", "r50", "--syncbn", "--batch", "1", "--hw", "97", "129", "--steps", "2",
+                  "--warmup", "1")
+    assert line["n_gpus"] == 2 and line["config"]["norm"] == "SyncBN"
+    assert line["config"]["parallelism"] == "dp2" and line["allreduce"]["distinct_devices"] == 2
+    assert line["allreduce"]["gradient"]["bytes"] > 100e6          # DDCN-R50 + DANet head: ~50 M fp32 parameters
+    assert line["final_loss"] == line["final_loss"] and line["final_loss"] > 0      # finite
+
+
+def test_bench_single_gpu_line_has_the_contract_fields():
+    line = _bench("--steps", "3", "--warmup", "1", "--no-cpu-baseline")
+    assert line["n_gpus"] == 1 and line["metric"] == "DDCN op fwd+bwd GB/s" and line["dtype"] == "f32"
+    assert line["roofline"]["bound"] == "mfma" and 0 < line["roofline"]["frac"] <= 1
+    assert "traffic_source" in line["roofline"] and line["gather_GBps_executed"] > 0

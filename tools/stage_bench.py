@@ -14,6 +14,6 @@ for kv in [a for a in sys.argv[1:] if "=" in a]:
     w[k] = int(v)
 only = [a for a in sys.argv[1:] if "=" not in a]
 t = bench.make_inputs(w, torch.device("cuda:0"), 0)
-for r in bench.kernel_rooflines(w, t, 20):
+for r in bench.kernel_rooflines(w, t, 20)[0]:
     if not only or r["kernel"] in only:
         print("%-14s %.4f ms  %8.1f %s  frac %.3f" % (r["kernel"], r["ms"], r["achieved"], r["unit"], r["frac"]))
