@@ -116,6 +116,14 @@ int ddcn_deform_conv_forward_f32(const float *x, const float *weight, const floa
 int ddcn_deform_conv_direct_forward_f32(const float *x, const float *weight, const float *bias, const float *offset,
                                         float *out, int sigmoid, void *workspace, size_t workspace_bytes,
                                         const ddcn_geom *g, void *stream);
+/* The backward of the direct forward above (same coverage; anything else behaves like ddcn_deform_conv_backward_f32):
+ * gx, goff as H:299-323, but the weight gradient (H:325-346: a second im2col into the columns tensor, then a Co-row
+ * GEMM) is formed by ONE kernel that samples x again and multiplies the samples into Co x 9 accumulators per input
+ * channel -- no columns are written or read for it.  grad_out is the gradient w.r.t. the PRE-activation value (the
+ * caller applies the sigmoid derivative).  ACCUMULATES into gx, goff, gw, gb like the other backward entry points. */
+int ddcn_deform_conv_direct_backward_f32(const float *x, const float *weight, const float *offset,
+                                         const float *grad_out, float *gx, float *goff, float *gw, float *gb,
+                                         void *workspace, size_t workspace_bytes, const ddcn_geom *g, void *stream);
 /* replaces deform_conv_cuda_backward (H:253-367) */
 int ddcn_deform_conv_backward_f32(const float *x, const float *weight, const float *offset, const float *grad_out,
                                   float *gx, float *goff, float *gw, float *gb, void *workspace,
@@ -174,6 +182,9 @@ int ddcn_deform_conv_forward_f64(const double *x, const double *weight, const do
 int ddcn_deform_conv_direct_forward_f64(const double *x, const double *weight, const double *bias,
                                         const double *offset, double *out, int sigmoid, void *workspace,
                                         size_t workspace_bytes, const ddcn_geom *g, void *stream);
+int ddcn_deform_conv_direct_backward_f64(const double *x, const double *weight, const double *offset,
+                                         const double *grad_out, double *gx, double *goff, double *gw, double *gb,
+                                         void *workspace, size_t workspace_bytes, const ddcn_geom *g, void *stream);
 int ddcn_deform_conv_backward_f64(const double *x, const double *weight, const double *offset, const double *grad_out,
                                   double *gx, double *goff, double *gw, double *gb, void *workspace,
                                   size_t workspace_bytes, const ddcn_geom *g, void *stream);

@@ -255,6 +255,28 @@ int ddcn_deform_conv_direct_forward_f32(const float *x, const float *weight, con
     return DDCN_OK;
 }
 
+int ddcn_deform_conv_direct_backward_f32(const float *x, const float *weight, const float *offset,
+                                         const float *grad_out, float *gx, float *goff, float *gw, float *gb,
+                                         void *workspace, size_t workspace_bytes, const ddcn_geom *g, void *stream)
+{
+    REQUIRE(x); REQUIRE(weight); REQUIRE(offset); REQUIRE(grad_out); REQUIRE(gx); REQUIRE(goff); REQUIRE(gw);
+    TRY(check_geom(g));
+    TRY(check_ws(g, workspace, workspace_bytes));
+    hipStream_t s = (hipStream_t)stream;
+    float *col = (float *)workspace;
+    TRY(launch_gemm_gcol(weight, grad_out, col, *g, s));
+    TRY(launch_col2im_coord(col, x, offset, nullptr, gx, goff, nullptr, *g, s, /*clear_coord=*/false));
+    bool handled = false;
+    // no second im2col, no 9-row G3 (the column gradients in the workspace are dead now: it takes the sample table)
+    TRY(launch_skinny_gweight(x, offset, grad_out, gw, workspace, workspace_bytes, *g, s, &handled));
+    if (!handled) {
+        TRY(launch_im2col(x, offset, nullptr, col, *g, s));
+        TRY(launch_gemm_gweight(grad_out, col, gw, *g, s));
+    }
+    if (gb) TRY(launch_bias_grad(grad_out, gb, *g, s));
+    return DDCN_OK;
+}
+
 int ddcn_deform_conv_backward_f32(const float *x, const float *weight, const float *offset, const float *grad_out,
                                   float *gx, float *goff, float *gw, float *gb, void *workspace,
                                   size_t workspace_bytes, const ddcn_geom *g, void *stream)
@@ -406,6 +428,14 @@ int ddcn_deform_conv_backward_saved_f64(const double *x, const double *weight, c
 int ddcn_deform_conv_backward_f64(const double *x, const double *weight, const double *offset, const double *grad_out,
                                   double *gx, double *goff, double *gw, double *gb, void *workspace,
                                   size_t workspace_bytes, const ddcn_geom *g, void *stream)
+{
+    return ddcn_deform_conv_backward_saved_f64(x, weight, offset, grad_out, nullptr, gx, goff, gw, gb, workspace,
+                                               workspace_bytes, g, stream);
+}
+
+int ddcn_deform_conv_direct_backward_f64(const double *x, const double *weight, const double *offset,
+                                         const double *grad_out, double *gx, double *goff, double *gw, double *gb,
+                                         void *workspace, size_t workspace_bytes, const ddcn_geom *g, void *stream)
 {
     return ddcn_deform_conv_backward_saved_f64(x, weight, offset, grad_out, nullptr, gx, goff, gw, gb, workspace,
                                                workspace_bytes, g, stream);

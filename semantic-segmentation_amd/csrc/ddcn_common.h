@@ -55,6 +55,8 @@ int launch_im2col(const float *x, const float *offset, const float *mask, float 
 int launch_skinny_forward(const float *x, const float *offset, const float *weight, const float *bias, float *out,
                           int sigmoid, void *ws, size_t ws_bytes, const ddcn_geom &g, hipStream_t stream, bool *handled);
 int launch_sigmoid_inplace(float *out, long count, hipStream_t stream);
+int launch_skinny_gweight(const float *x, const float *offset, const float *gpre, float *gw, void *ws, size_t ws_bytes,
+                          const ddcn_geom &g, hipStream_t stream, bool *handled);
 int launch_im2col_tiled(const float *x, const float *offset, const float *mask, float *col, const ddcn_geom &g,
                         hipStream_t stream, bool *handled);
 int launch_col2im_coord(const float *gcol, const float *x, const float *offset, const float *mask, float *gx,

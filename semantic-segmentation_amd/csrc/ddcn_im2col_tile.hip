@@ -19,6 +19,8 @@
 //     from global memory with the reference's own guards.
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "ddcn_common.h"
 
 namespace ddcn {
@@ -456,6 +458,239 @@ int launch_skinny_forward(const float *x, const float *offset, const float *weig
     hipLaunchKernelGGL(skinny_finish_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, (const float *)ws, bias, out,
                        per_grp, a.groups, g.Co, a.P, sigmoid);
     return check_launch("skinny_finish");
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Weight gradient of a deformable convolution with FEW output channels, without columns (the backward twin of the
+// direct forward above; the DDCN layer's mask branch, detseg/ops/dcn/deform_conv.py:438-446):
+//     gw[o][c][k] += sum_{n,p} gpre[n][o][p] * sample(x[n][c], p, k)          (G3, deform_conv_cuda.cpp:341-346)
+// where sample() is the bilinear value the forward's im2col would have written (K:189-242).  The reference re-runs
+// im2col into its columns tensor (H:325-327: 86.7 MB per image for this branch) and multiplies by a 9-row matrix.
+// Here a workgroup owns ONE input channel and a slice of the pixel strips of one image: per strip of 256 consecutive
+// pixels it stages the channel's patch rows in LDS, every lane samples its pixel's nine taps and multiplies them into
+// Co x 9 register accumulators; after the last strip the accumulators are summed over the workgroup (wave butterflies,
+// then LDS) and added to gw with one atomic per (o, k).  Nothing but x, offset and gpre is read.
+struct SkinnyGwArgs {
+    const float *x, *gpre;
+    const float *tab;    // sample table [N][9][3][P]: (hl << 16 | wl & 0xffff) bits, lh, lw; hl = -32768: sample invalid
+    float *gw;
+    ddcn_geom g;
+    int P, co;
+    int slices, tiles, tiles_per_slice;
+    int M, RH, RW, RS;
+};
+
+// Sample table: the per-(pixel, tap) part of the bilinear gather -- integer corner and fractional parts, K:226-233 --
+// computed once and streamed by every channel's workgroup below (the coordinate arithmetic is ~100 instructions per
+// sample; recomputed per channel it was 10x the useful work of the weight-gradient kernel).
+constexpr int TAB_INVALID = -32768;
+__global__ __launch_bounds__(256) void sample_table_kernel(const float *offset, float *tab, ddcn_geom g, int P)
+{
+    constexpr int K2 = 9;
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    if (p >= P) return;
+    const int k = blockIdx.y, n = blockIdx.z;
+    const int ho = p / g.Wo, wo = p - ho * g.Wo;
+    const int i = k / 3, j = k - 3 * i;
+    const float *off = offset + ((long)n * 2 * K2 + 2 * k) * P + p;
+    const float h = (float)(ho * g.sh - g.ph + i * g.dh) + off[0];
+    const float w = (float)(wo * g.sw - g.pw + j * g.dw) + off[P];
+    const float fhl = floorf(h), fwl = floorf(w);
+    const bool valid = h > -1.f && w > -1.f && h < (float)g.H && w < (float)g.W;
+    const int hl = valid ? (int)fhl : TAB_INVALID, wl = valid ? (int)fwl : 0;
+    float *dst = tab + ((long)n * K2 + k) * 3 * P + p;
+    dst[0] = __int_as_float((hl << 16) | (wl & 0xffff));
+    dst[P] = h - fhl;
+    dst[2 * (long)P] = w - fwl;
+}
+
+// Sum of v over the 64 lanes of a wave, valid in lane 63: four DPP steps reduce each row of 16 lanes, two row
+// broadcasts carry the row sums up (the sequence rocPRIM uses on GFX9-class targets).
+__device__ __forceinline__ float wave_sum_to_lane63(float v)
+{
+    auto dpp = [](float x, auto ctrl, auto row_mask) {
+        return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), decltype(ctrl)::value,
+                                                                     decltype(row_mask)::value, 0xf, false));
+    };
+    v += dpp(v, std::integral_constant<int, 0x111>{}, std::integral_constant<int, 0xf>{});   // row_shr:1
+    v += dpp(v, std::integral_constant<int, 0x112>{}, std::integral_constant<int, 0xf>{});   // row_shr:2
+    v += dpp(v, std::integral_constant<int, 0x114>{}, std::integral_constant<int, 0xf>{});   // row_shr:4
+    v += dpp(v, std::integral_constant<int, 0x118>{}, std::integral_constant<int, 0xf>{});   // row_shr:8 -> lane 15 of each row
+    v += dpp(v, std::integral_constant<int, 0x142>{}, std::integral_constant<int, 0xa>{});   // row_bcast:15 into rows 1, 3
+    v += dpp(v, std::integral_constant<int, 0x143>{}, std::integral_constant<int, 0xc>{});   // row_bcast:31 into rows 2, 3
+    return v;
+}
+
+template <int COMAX, int NCELL>
+__global__ __launch_bounds__(IT, 2) void skinny_gweight_kernel(SkinnyGwArgs a)
+{
+    constexpr int K2 = 9;
+    extern __shared__ __attribute__((aligned(16))) float smem[];   // xs[RS] patch of one channel, then red[4][COMAX * 9]
+    const ddcn_geom &g = a.g;
+    const int t = threadIdx.x;
+    const int c = blockIdx.x, slice = blockIdx.y, n = blockIdx.z;
+    const int HW = g.H * g.W;
+    const __amdgpu_buffer_rsrc_t rx = mk_rsrc(a.x + ((long)n * g.C + c) * HW, (long)HW * 4);
+    const float *xc = a.x + ((long)n * g.C + c) * HW;
+    const float *tab = a.tab + (long)n * K2 * 3 * a.P;
+    const float *gp_base = a.gpre + (long)n * a.co * a.P;
+    float *xs = smem;
+
+    float acc[COMAX][K2];
+#pragma unroll
+    for (int o = 0; o < COMAX; ++o)
+#pragma unroll
+        for (int k = 0; k < K2; ++k) acc[o][k] = 0.f;
+
+    // patch cell i = t + 256 j -> (row, image column) inside the patch; the patch's first image row moves with the strip
+    int prow[NCELL], pcol[NCELL];
+#pragma unroll
+    for (int j = 0; j < NCELL; ++j) {
+        const int i = t + IT * j;
+        prow[j] = i / a.RW;
+        pcol[j] = i - prow[j] * a.RW - 1;          // patch columns are image columns -1 .. W
+        if (i >= a.RS || pcol[j] < 0 || pcol[j] >= g.W) prow[j] = -(1 << 20);   // never inside the image
+    }
+    float stg[NCELL], tl[K2], th[K2], tw[K2], gp[COMAX];
+    // everything strip `tile` needs from global memory goes in flight at once (out-of-image cells read 0 through an
+    // out-of-range buffer offset == the reference's zero for out-of-image corners, K:97-108)
+    auto fetch = [&](int tile) {
+        const int rh0 = (tile * IT / g.Wo) * g.sh - g.ph - a.M;
+        const int pix = tile * IT + t;
+        const int p = pix < a.P ? pix : 0;
+#pragma unroll
+        for (int j = 0; j < NCELL; ++j) {
+            const int y = rh0 + prow[j];
+            const unsigned o = (y >= 0 && y < g.H) ? (unsigned)((y * g.W + pcol[j]) * 4) : OOBV;
+            stg[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rx, o, 0, 0));
+        }
+        const float *tp = tab + p;
+#pragma unroll
+        for (int k = 0; k < K2; ++k) {
+            tl[k] = tp[(long)(3 * k) * a.P];
+            th[k] = tp[(long)(3 * k + 1) * a.P];
+            tw[k] = tp[(long)(3 * k + 2) * a.P];
+        }
+#pragma unroll
+        for (int o = 0; o < COMAX; ++o) gp[o] = (o < a.co) ? gp_base[(long)o * a.P + p] : 0.f;
+    };
+
+    const int tile_beg = slice * a.tiles_per_slice;
+    const int tile_end = min(a.tiles, tile_beg + a.tiles_per_slice);
+    if (tile_beg < tile_end) fetch(tile_beg);
+    for (int tile = tile_beg; tile < tile_end; ++tile) {
+        const bool live = tile * IT + t < a.P;
+        const int rh0 = (tile * IT / g.Wo) * g.sh - g.ph - a.M;
+#pragma unroll
+        for (int j = 0; j < NCELL; ++j)
+            if (t + IT * j < a.RS) xs[t + IT * j] = stg[j];
+        // this strip's samples out of the prefetch registers, then the next strip's loads
+        int chw[K2];
+        float clh[K2], clw[K2], cgp[COMAX];
+#pragma unroll
+        for (int k = 0; k < K2; ++k) {
+            chw[k] = live ? __float_as_int(tl[k]) : (TAB_INVALID << 16);
+            clh[k] = th[k]; clw[k] = tw[k];
+        }
+#pragma unroll
+        for (int o = 0; o < COMAX; ++o) cgp[o] = gp[o];
+        __syncthreads();
+        if (tile + 1 < tile_end) fetch(tile + 1);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int k = 0; k < K2; ++k) {
+            const int hl = chw[k] >> 16, wl = (int)(short)(chw[k] & 0xffff);
+            float val = 0.f;
+            if (hl != TAB_INVALID) {
+                const float lh = clh[k], lw = clw[k];
+                const float hh = 1.f - lh, hw = 1.f - lw;
+                const int rr = hl - rh0, rc = wl + 1;
+                float v1, v2, v3, v4;
+                if (rr >= 0 && rr + 1 < a.RH) {          // wl in [-1, W-1] always holds for a valid sample
+                    const int ci = rr * a.RW + rc;
+                    v1 = xs[ci]; v2 = xs[ci + 1]; v3 = xs[ci + a.RW]; v4 = xs[ci + a.RW + 1];
+                } else {                                  // the sample left the staged rows: the reference's own guards
+                    const bool ok1 = hl >= 0 && wl >= 0, ok2 = hl >= 0 && wl + 1 <= g.W - 1;
+                    const bool ok3 = hl + 1 <= g.H - 1 && wl >= 0, ok4 = hl + 1 <= g.H - 1 && wl + 1 <= g.W - 1;
+                    const int gi = hl * g.W + wl;
+                    const float r1 = xc[ok1 ? gi : 0], r2 = xc[ok2 ? gi + 1 : 0];
+                    const float r3 = xc[ok3 ? gi + g.W : 0], r4 = xc[ok4 ? gi + g.W + 1 : 0];
+                    v1 = ok1 ? r1 : 0.f; v2 = ok2 ? r2 : 0.f; v3 = ok3 ? r3 : 0.f; v4 = ok4 ? r4 : 0.f;
+                }
+                val = (hh * hw * v1 + hh * lw * v2 + lh * hw * v3 + lh * lw * v4);
+            }
+#pragma unroll
+            for (int o = 0; o < COMAX; ++o) acc[o][k] += cgp[o] * val;
+        }
+        __syncthreads();   // every wave is done with the patch before the next strip overwrites it
+    }
+
+    // sum over the workgroup: DPP row reductions inside each wave (no LDS traffic), then the four waves through LDS
+    float *red = smem;     // the patch is dead (barrier above)
+    const int lane = t & 63, wave = t >> 6;
+#pragma unroll
+    for (int o = 0; o < COMAX; ++o)
+#pragma unroll
+        for (int k = 0; k < K2; ++k) {
+            const float v = wave_sum_to_lane63(acc[o][k]);
+            if (lane == 63) red[wave * (COMAX * K2) + o * K2 + k] = v;
+        }
+    __syncthreads();
+    if (t < COMAX * K2) {
+        const int o = t / K2, k = t - o * K2;
+        if (o < a.co) {
+            const float v = red[t] + red[COMAX * K2 + t] + red[2 * COMAX * K2 + t] + red[3 * COMAX * K2 + t];
+            atomicAdd(a.gw + ((long)o * g.C + c) * K2 + k, v);
+        }
+    }
+}
+
+// `ws` (>= 108 * N * P bytes, any contents) receives the sample table.
+int launch_skinny_gweight(const float *x, const float *offset, const float *gpre, float *gw, void *ws, size_t ws_bytes,
+                          const ddcn_geom &g, hipStream_t stream, bool *handled)
+{
+    *handled = false;
+    const Dims d = dims_of(g);
+    if (g.kh != 3 || g.kw != 3 || g.groups != 1 || g.dg != 1 || g.Co > SKMAX) return DDCN_OK;
+    if ((long)g.C * g.H * g.W >= (1L << 31) || g.N > 65535 || g.C > 0x7fffffff) return DDCN_OK;
+    if (g.H >= 32766 || g.W >= 32766 || (size_t)g.N * 9 * 3 * d.P * sizeof(float) > ws_bytes) return DDCN_OK;
+    static const int env_on = getenv("DDCN_SKINNY_GW") ? atoi(getenv("DDCN_SKINNY_GW")) : 1;
+    if (!env_on) return DDCN_OK;
+    SkinnyGwArgs a{};
+    static const int env_m = getenv("DDCN_TILE_MARGIN") ? atoi(getenv("DDCN_TILE_MARGIN")) : 6;
+    a.M = env_m < 0 ? 0 : env_m;
+    const int rows_span = (IT + g.Wo - 2) / g.Wo + 1;
+    a.RH = (rows_span - 1) * g.sh + 2 * g.dh + 2 + 2 * a.M;
+    a.RW = g.W + 2;
+    a.RS = a.RH * a.RW;
+    const size_t smem = sizeof(float) * (size_t)max(a.RS, 4 * SKMAX * 9);   // patch, later the wave sums
+    const int ncell = (a.RS + IT - 1) / IT;
+    if (ncell > 16 || (long)g.H * g.W * 4 >= (1L << 31)) return DDCN_OK;   // very wide maps: columns path
+    a.x = x; a.tab = (const float *)ws; a.gpre = gpre; a.gw = gw;
+    a.g = g; a.P = d.P; a.co = g.Co;
+    a.tiles = (d.P + IT - 1) / IT;
+    // enough workgroups to fill the chip (two per CU) a few times over, but no more slices than strips
+    int slices = (int)((2048 + (long)g.C * g.N - 1) / ((long)g.C * g.N));
+    if (slices < 1) slices = 1;
+    if (slices > a.tiles) slices = a.tiles;
+    a.tiles_per_slice = (a.tiles + slices - 1) / slices;
+    a.slices = (a.tiles + a.tiles_per_slice - 1) / a.tiles_per_slice;
+    if (a.slices > 65535) return DDCN_OK;
+    *handled = true;
+    hipLaunchKernelGGL(sample_table_kernel, dim3((unsigned)((d.P + 255) / 256), 9, (unsigned)g.N), dim3(256), 0, stream,
+                       offset, (float *)ws, g, d.P);
+    const dim3 grid((unsigned)g.C, (unsigned)a.slices, (unsigned)g.N);
+#define DDCN_SKGW_LAUNCH(CO)                                                                                  \
+    do {                                                                                                      \
+        if (ncell <= 4) hipLaunchKernelGGL((skinny_gweight_kernel<CO, 4>), grid, dim3(IT), smem, stream, a);  \
+        else if (ncell <= 8) hipLaunchKernelGGL((skinny_gweight_kernel<CO, 8>), grid, dim3(IT), smem, stream, a);   \
+        else if (ncell <= 12) hipLaunchKernelGGL((skinny_gweight_kernel<CO, 12>), grid, dim3(IT), smem, stream, a); \
+        else hipLaunchKernelGGL((skinny_gweight_kernel<CO, 16>), grid, dim3(IT), smem, stream, a);            \
+    } while (0)
+    if (g.Co <= 9) DDCN_SKGW_LAUNCH(9);      // the DDCN layer's mask branch: 9 output channels
+    else DDCN_SKGW_LAUNCH(SKMAX);
+#undef DDCN_SKGW_LAUNCH
+    return check_launch("skinny_gweight");
 }
 
 // out[i] = sigmoid(out[i]) (fallback of the direct entry point when the geometry is not covered)

@@ -396,7 +396,8 @@ class _DeformConvSigmoidFunction(Function):
     """sigmoid(deform_conv(input, offset, weight, bias)): the mask branch of the DDCN layer (PY:438-446, 457-458).
 
     Forward is ONE direct kernel for the few (9) output channels (ddcn_deform_conv_direct_forward_f32: no columns,
-    no 9-row GEMM, sigmoid fused); backward applies sigmoid' and then is DeformConvFunction's backward."""
+    no 9-row GEMM, sigmoid fused); backward applies sigmoid' and calls ddcn_deform_conv_direct_backward_f32 (the
+    weight gradient without a second im2col or a 9-row GEMM)."""
 
     @staticmethod
     def forward(ctx, input, offset, weight, bias, stride, padding, dilation, groups, deformable_groups):
@@ -441,7 +442,7 @@ class _DeformConvSigmoidFunction(Function):
         _expect_shape("grad_output", grad_pre, (g.N, g.Co, g.Ho, g.Wo))
         ws, ws_bytes = _workspace(input, g, cd)
         with torch.cuda.device(input.device):
-            _lib.check(_entry("ddcn_deform_conv_backward", cd)(
+            _lib.check(_entry("ddcn_deform_conv_direct_backward", cd)(
                 _lib.ptr(input), _lib.ptr(weight), _lib.ptr(offset), _lib.ptr(grad_pre), _lib.ptr(grad_input),
                 _lib.ptr(grad_offset), _lib.ptr(grad_weight), _lib.ptr(grad_bias) if ctx.with_bias else None,
                 _lib.ptr(ws), ws_bytes, g, _lib.current_stream(input.device)))

@@ -1,0 +1,103 @@
+"""GPU parity of the direct (no-columns) entry points for deformable convolutions with few output channels -- the mask
+branch of the DDCN layer (detseg/ops/dcn/deform_conv.py:438-446, 457-458) -- straight through the C ABI, against the
+fp64 oracle on the same fp32-rounded inputs.  Bars: forward <= 1e-5, backward <= 1e-4 (rel-err = max|a-b| / max|b|)."""
+import importlib
+
+import numpy as np
+import pytest
+import torch
+
+import cases
+from helpers import BWD_TOL, FWD_TOL
+from oracle import ddcn_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+if torch.cuda.is_available():
+    _lib = importlib.import_module("semantic-segmentation_amd.dcn._lib")
+DEV = "cuda:0"
+
+DIRECT_CASES = [
+    cases.C("mask_branch_c64_33x29_d2", N=2, Ci=64, Co=9, H=33, W=29, pad=2, dil=2, bias=True, modulated=False, seed=50),
+    cases.C("mask_branch_c32_97x97_d4", N=1, Ci=32, Co=9, H=97, W=97, pad=4, dil=4, bias=True, modulated=False, seed=51),
+    cases.C("co12_stride2", N=2, Ci=16, Co=12, H=41, W=37, stride=2, pad=1, dil=1, modulated=False, seed=52),
+    cases.C("co1_scattered", N=2, Ci=8, Co=1, H=19, W=23, pad=1, dil=1, off_scale=9.0, bias=True, modulated=False, seed=53),
+    cases.C("tiny_4x4", N=1, Ci=4, Co=9, H=4, W=4, pad=1, dil=1, modulated=False, seed=54),
+    # outside the direct kernels (Co > 12, deformable groups, 5x5): the entry points fall back to columns + GEMM
+    cases.C("fallback_co16", N=1, Ci=8, Co=16, H=11, W=13, pad=1, dil=1, bias=True, modulated=False, seed=55),
+    cases.C("fallback_dg2", N=1, Ci=8, Co=9, H=11, W=13, pad=2, dil=2, dg=2, modulated=False, seed=56),
+    cases.C("fallback_5x5", N=1, Ci=4, Co=4, H=9, W=9, kh=5, kw=5, pad=2, dil=1, modulated=False, seed=57),
+]
+
+
+def _dev(a):
+    return None if a is None else torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(DEV)
+
+
+@pytest.mark.parametrize("c", DIRECT_CASES, ids=lambda c: c["name"])
+def test_direct_forward_and_backward_match_oracle(c):
+    L = _lib.lib()
+    inp = {k: (None if v is None else v.astype(np.float32).astype(np.float64)) for k, v in cases.make_inputs(c).items()}
+    Ho, Wo, _ = cases.geometry(c)
+    g = _lib.Geom(c["N"], c["Ci"], c["H"], c["W"], c["Co"], c["kh"], c["kw"], c["stride"], c["stride"], c["pad"],
+                  c["pad"], c["dil"], c["dil"], c["groups"], c["dg"], Ho, Wo)
+    x, w, off, gout = _dev(inp["x"]), _dev(inp["weight"]), _dev(inp["offset"]), _dev(inp["gout"])
+    b = _dev(inp["bias"]) if c["bias"] else None
+    s = _lib.current_stream(torch.device(DEV))
+    nbytes = L.ddcn_workspace_bytes(g)
+    ws = torch.empty(max(nbytes // 4, 4), device=DEV)
+    kw = cases.kwargs(c)
+
+    for sigmoid in (0, 1):
+        out = torch.full((c["N"], c["Co"], Ho, Wo), float("nan"), device=DEV)
+        _lib.check(L.ddcn_deform_conv_direct_forward_f32(_lib.ptr(x), _lib.ptr(w), _lib.ptr(b), _lib.ptr(off),
+                                                         _lib.ptr(out), sigmoid, _lib.ptr(ws), nbytes, g, s))
+        exp = orc.deform_forward(inp["x"], inp["offset"], None, inp["weight"], inp["bias"], **kw)
+        if sigmoid:
+            exp = 1.0 / (1.0 + np.exp(-exp))
+        assert cases.relerr(out.cpu().numpy(), exp) <= FWD_TOL, (sigmoid, cases.relerr(out.cpu().numpy(), exp))
+
+    gx, goff, gw = torch.zeros_like(x), torch.zeros_like(off), torch.zeros_like(w)
+    gb = torch.zeros(c["Co"], device=DEV) if c["bias"] else None
+    _lib.check(L.ddcn_deform_conv_direct_backward_f32(_lib.ptr(x), _lib.ptr(w), _lib.ptr(off), _lib.ptr(gout),
+                                                      _lib.ptr(gx), _lib.ptr(goff), _lib.ptr(gw), _lib.ptr(gb),
+                                                      _lib.ptr(ws), nbytes, g, s))
+    torch.cuda.synchronize()
+    egx, egoff, _, egw, egb = orc.deform_backward(inp["x"], inp["offset"], None, inp["weight"], inp["gout"], c["bias"],
+                                                  **kw)
+    assert cases.relerr(gx.cpu().numpy(), egx) <= BWD_TOL
+    assert cases.relerr(goff.cpu().numpy(), egoff) <= BWD_TOL
+    assert cases.relerr(gw.cpu().numpy(), egw) <= BWD_TOL, cases.relerr(gw.cpu().numpy(), egw)
+    if c["bias"]:
+        assert cases.relerr(gb.cpu().numpy(), egb) <= BWD_TOL
+    # backward ACCUMULATES: a second call doubles every gradient
+    _lib.check(L.ddcn_deform_conv_direct_backward_f32(_lib.ptr(x), _lib.ptr(w), _lib.ptr(off), _lib.ptr(gout),
+                                                      _lib.ptr(gx), _lib.ptr(goff), _lib.ptr(gw), _lib.ptr(gb),
+                                                      _lib.ptr(ws), nbytes, g, s))
+    torch.cuda.synchronize()
+    assert cases.relerr(gw.cpu().numpy(), 2 * egw) <= BWD_TOL and cases.relerr(gx.cpu().numpy(), 2 * egx) <= BWD_TOL
+
+
+def test_direct_backward_full_size_mask_branch_against_oracle():
+    """The res5 mask branch at full size: depth 256 -> 9, 97x97, pad = dil = 4, one image, raw randn offsets against
+    the fp32 oracle (same cells, see tests/test_gpu_fullsize.py)."""
+    L = _lib.lib()
+    gen = torch.Generator(device="cpu").manual_seed(77)
+    x = torch.randn(1, 256, 97, 97, generator=gen)
+    w = torch.randn(9, 256, 3, 3, generator=gen) * 0.02
+    off = torch.randn(1, 18, 97, 97, generator=gen) * 2
+    gout = torch.randn(1, 9, 97, 97, generator=gen)
+    g = _lib.Geom(1, 256, 97, 97, 9, 3, 3, 1, 1, 4, 4, 4, 4, 1, 1, 97, 97)
+    xd, wd, od, gd = (t.to(DEV) for t in (x, w, off, gout))
+    gx, goff, gw = torch.zeros_like(xd), torch.zeros_like(od), torch.zeros_like(wd)
+    nbytes = L.ddcn_workspace_bytes(g)
+    ws = torch.empty(nbytes // 4, device=DEV)
+    _lib.check(L.ddcn_deform_conv_direct_backward_f32(_lib.ptr(xd), _lib.ptr(wd), _lib.ptr(od), _lib.ptr(gd),
+                                                      _lib.ptr(gx), _lib.ptr(goff), _lib.ptr(gw), None, _lib.ptr(ws),
+                                                      nbytes, g, _lib.current_stream(torch.device(DEV))))
+    torch.cuda.synchronize()
+    f32 = lambda t: np.ascontiguousarray(t.numpy(), dtype=np.float32)
+    egx, egoff, _, egw, _ = orc.deform_backward(f32(x), f32(off), None, f32(w), f32(gout), False, 1, 4, 4, 1, 1)
+    assert cases.relerr(gx.cpu().numpy(), egx) <= BWD_TOL
+    assert cases.relerr(goff.cpu().numpy(), egoff) <= BWD_TOL
+    assert cases.relerr(gw.cpu().numpy(), egw) <= BWD_TOL
