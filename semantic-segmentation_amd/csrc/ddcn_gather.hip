@@ -217,33 +217,50 @@ __global__ __launch_bounds__(GT) void depthaware_im2col_kernel(GatherArgs a)
     }
 }
 
-// K:952-996.  Same grid; scatter with atomics (taps of neighbouring pixels overlap).
+// K:952-996 as a GATHER.  The reference scatters col * exp(-|Di - Dval|) to gI[h_im, w_im] with one atomic per
+// (channel, tap, pixel).  The taps sit on the integer grid, so every input cell (y, x) knows which output pixel reaches
+// it through tap (i, j): ho = (y + ph - i*dh) / sh when that division is exact and in range (same for wo).  One lane owns
+// one input cell: it resolves its <= K2 (pixel, similarity) pairs once, sums the column gradients of DA_CH channels in
+// registers in ascending tap order and adds each sum to grad_input with a plain read-modify-write -- no atomics, no
+// contention, deterministic.  grid: (ceil(H*W/256), C/DA_CH, N).
+constexpr int DA_CH = 8;
 __global__ __launch_bounds__(GT) void depthaware_col2im_kernel(GatherArgs a)
 {
     const ddcn_geom &g = a.g;
-    const int p = blockIdx.x * GT + threadIdx.x;
-    if (p >= a.P) return;
-    const int c0 = blockIdx.y * a.CH;
+    const int cell = blockIdx.x * GT + threadIdx.x;
+    const int HWi = g.H * g.W;
+    if (cell >= HWi) return;
+    const int c0 = blockIdx.y * DA_CH;
     const int n = blockIdx.z;
-    const int ho = p / g.Wo, wo = p - ho * g.Wo;
-    const int h_in = ho * g.sh - g.ph, w_in = wo * g.sw - g.pw;
-    const long HW = (long)g.H * g.W;
-    const float *dp = a.depth + (long)n * HW;
-    float *gxb = a.gx + ((long)n * g.C + c0) * HW;
-    const float *gcb = a.gcol + ((long)n * g.C * a.K2 + (long)c0 * a.K2) * a.ld + p;
-    const int hc = h_in + g.dh * (g.kh - 1) / 2, wc = w_in + g.dw * (g.kw - 1) / 2;
-    const bool valid = hc >= 0 && wc >= 0 && hc < g.H && wc < g.W;
-    const float Di = valid ? dp[hc * g.W + wc] : 0.f;
+    const int y = cell / g.W, x = cell - y * g.W;
+    const float *dp = a.depth + (long)n * HWi;
+    const float Dcell = dp[cell];
+    const float *gcb = a.gcol + ((long)n * g.C + c0) * a.K2 * a.ld;
+    const int nch = min(DA_CH, g.C - c0);
+    float acc[DA_CH];
+#pragma unroll
+    for (int c = 0; c < DA_CH; ++c) acc[c] = 0.f;
     for (int k = 0; k < a.K2; ++k) {
         const int i = k / g.kw, j = k - i * g.kw;
-        const int h_im = h_in + i * g.dh, w_im = w_in + j * g.dw;
-        const bool inb = h_im >= 0 && w_im >= 0 && h_im < g.H && w_im < g.W;
-        if (!inb) continue;
-        const int idx = h_im * g.W + w_im;
-        const float Dval = valid ? dp[idx] : 0.f;
+        const int th = y + g.ph - i * g.dh, tw = x + g.pw - j * g.dw;
+        if (th < 0 || tw < 0) continue;
+        const int ho = th / g.sh, wo = tw / g.sw;
+        if (ho * g.sh != th || wo * g.sw != tw || ho >= g.Ho || wo >= g.Wo) continue;
+        // similarity of output pixel (ho, wo) and this tap, K:970-986: centre outside the map -> both depths read as 0
+        const int hc = ho * g.sh - g.ph + g.dh * (g.kh - 1) / 2, wc = wo * g.sw - g.pw + g.dw * (g.kw - 1) / 2;
+        const bool valid = hc >= 0 && wc >= 0 && hc < g.H && wc < g.W;
+        const float Di = valid ? dp[hc * g.W + wc] : 0.f;
+        const float Dval = valid ? Dcell : 0.f;
         const float sim = expf(-fabsf(Di - Dval));
-        for (int c = 0; c < a.CH; ++c) atomicAdd(gxb + c * HW + idx, gcb[((long)c * a.K2 + k) * a.ld] * sim);
+        const float *src = gcb + (long)k * a.ld + (ho * g.Wo + wo);
+#pragma unroll
+        for (int c = 0; c < DA_CH; ++c)
+            if (c < nch) acc[c] += src[(long)c * a.K2 * a.ld] * sim;
     }
+    float *dst = a.gx + ((long)n * g.C + c0) * HWi + cell;
+#pragma unroll
+    for (int c = 0; c < DA_CH; ++c)
+        if (c < nch) dst[(long)c * HWi] += acc[c];
 }
 
 // ---------------------------------------------------------------------------------------- bias grad
@@ -343,8 +360,8 @@ int launch_depthaware_col2im(const float *gcol, const float *depth, float *gx, c
 {
     GatherArgs a = base_args(g);
     a.gcol = gcol; a.depth = depth; a.gx = gx;
-    a.CH = pick_chunk(g.C, 16, 1);
-    dim3 grid((a.P + GT - 1) / GT, g.C / a.CH, g.N);
+    const long cells = (long)g.H * g.W;
+    dim3 grid((unsigned)((cells + GT - 1) / GT), (g.C + DA_CH - 1) / DA_CH, g.N);
     if (grid.y > 65535 || grid.z > 65535) return fail(DDCN_ERR_UNSUPPORTED, "depthaware_col2im: grid too large");
     hipLaunchKernelGGL(depthaware_col2im_kernel, grid, dim3(GT), 0, stream, a);
     return check_launch("depthaware_col2im");

@@ -55,3 +55,20 @@ def test_bench_single_gpu_line_has_the_contract_fields():
     assert line["n_gpus"] == 1 and line["metric"] == "DDCN op fwd+bwd GB/s" and line["dtype"] == "f32"
     assert line["roofline"]["bound"] == "mfma" and 0 < line["roofline"]["frac"] <= 1
     assert "traffic_source" in line["roofline"] and line["gather_GBps_executed"] > 0
+
+
+def test_train_cli_runs_and_resumes(tmp_path):
+    """tools/train.py (the reference's tools/train.py:15-109 shape): two iterations, a checkpoint, a resumed run."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    base = [sys.executable, os.path.join(ROOT, "tools", "train.py"), "danet_r50_depthdeform", "--crop", "65", "97",
+            "--imgs_per_gpu", "1", "--log_interval", "1", "--seed", "3"]
+    r = subprocess.run(base + ["--iters", "2", "--work_dir", str(tmp_path)], env=env, capture_output=True, text=True,
+                       timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    logs = [json.loads(l) for l in r.stdout.splitlines() if l.startswith("{")]
+    assert [l["iter"] for l in logs if "iter" in l] == [1, 2] and logs[-1]["checkpoint"].endswith("iter_2.pth")
+    r2 = subprocess.run(base + ["--iters", "1", "--resume_from", logs[-1]["checkpoint"]], env=env, capture_output=True,
+                        text=True, timeout=600)
+    assert r2.returncode == 0, r2.stderr[-2000:]
+    logs2 = [json.loads(l) for l in r2.stdout.splitlines() if l.startswith("{")]
+    assert logs2[0]["iter"] == 3 and logs2[0]["loss"] == logs2[0]["loss"]

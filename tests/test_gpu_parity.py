@@ -94,6 +94,37 @@ def test_hip_depthaware_matches_golden(c):
         assert cases.relerr(b.grad.cpu().numpy(), g["gb"]) <= BWD_TOL
 
 
+DA_MEDIUM = [
+    cases.C("da_med_c64_33x29_d2", N=2, Ci=64, Co=48, H=33, W=29, pad=2, dil=2, bias=True, seed=45),
+    cases.C("da_med_c20_41x37_s2", N=2, Ci=20, Co=24, H=41, W=37, stride=2, pad=1, dil=1, seed=46),   # C % 8 != 0
+    cases.C("da_med_c16_30x30_s2_d3_g2", N=1, Ci=16, Co=16, H=30, W=30, stride=2, pad=4, dil=3, groups=2, seed=47),
+]
+
+
+@pytest.mark.parametrize("c", DA_MEDIUM, ids=lambda c: c["name"])
+def test_hip_depthaware_medium_against_oracle(c):
+    """Depth-aware conv at sizes that span many workgroups; grad_input comes from the gather formulation of K:952-996
+    (one lane per input cell, no atomics), so a second run must give the same bits."""
+    inp = _r32(cases.make_inputs(c))
+    kw = dict(stride=c["stride"], padding=c["pad"], dilation=c["dil"], groups=c["groups"])
+    eout = orc.depthaware_forward(inp["x"], inp["depth"], inp["weight"], inp["bias"], **kw)
+    egx, egw, egb = orc.depthaware_backward(inp["x"], inp["depth"], inp["weight"], inp["gout"], c["bias"], **kw)
+
+    def run():
+        x, w = _t(inp["x"], True), _t(inp["weight"], True)
+        b = _t(inp["bias"], True) if c["bias"] else None
+        out = pkg.depthaware_conv(x, _t(inp["depth"]), w, b, c["stride"], c["pad"], c["dil"], c["groups"])
+        out.backward(_t(inp["gout"]))
+        return out.detach(), x.grad, w.grad, (b.grad if c["bias"] else None)
+    out, gx, gw, gb = run()
+    assert cases.relerr(out.cpu().numpy(), eout) <= FWD_TOL
+    assert cases.relerr(gx.cpu().numpy(), egx) <= BWD_TOL
+    assert cases.relerr(gw.cpu().numpy(), egw) <= BWD_TOL
+    if c["bias"]:
+        assert cases.relerr(gb.cpu().numpy(), egb) <= BWD_TOL
+    assert torch.equal(run()[1], gx)          # deterministic grad_input
+
+
 # ---------------------------------------------------------------- stage level, straight through the C ABI
 def _geom(c):
     Ho, Wo, _ = cases.geometry(c)
