@@ -161,6 +161,18 @@ int ddcn_modulated_deform_conv_backward_saved_f32(const float *x, const float *w
                                                   float *gx, float *goff, float *gmask, float *gw, float *gb,
                                                   void *workspace, size_t workspace_bytes, const ddcn_geom *g,
                                                   void *stream);
+/* The saved-columns backward on TWO streams of the caller (mask / gmask NULL: the non-modulated op).  The reference
+ * runs its backward stages one after the other (H:497-561); here the weight-gradient GEMM (G3, + G4), which depends only
+ * on grad_out and the saved columns, is launched on `side_stream` beside the LDS-atomic-bound scatter, which then runs
+ * in a variant small enough to share each CU with the resident GEMM workgroup.  `fork_event` / `join_event` are two
+ * hipEvent_t of the caller (the library creates nothing): fork is recorded on `stream` behind G2, `side_stream` waits
+ * for it; join is recorded on `side_stream` after G3 and `stream` waits for it before the call's work counts as done, so
+ * the caller sees single-stream semantics on `stream`.  Everything else as the *_backward_saved_f32 entry points. */
+int ddcn_deform_conv_backward_saved_2s_f32(const float *x, const float *weight, const float *offset,
+                                           const float *mask, const float *grad_out, const float *columns, float *gx,
+                                           float *goff, float *gmask, float *gw, float *gb, void *workspace,
+                                           size_t workspace_bytes, const ddcn_geom *g, void *stream, void *side_stream,
+                                           void *fork_event, void *join_event);
 /* replaces depthaware_conv_cuda_forward (H:567-647) */
 int ddcn_depthaware_conv_forward_f32(const float *x, const float *depth, const float *weight, const float *bias,
                                      float *out, void *workspace, size_t workspace_bytes, const ddcn_geom *g,

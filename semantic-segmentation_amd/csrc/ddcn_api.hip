@@ -209,18 +209,43 @@ static int deform_forward(const float *x, const float *weight, const float *bias
     return DDCN_OK;
 }
 
+// Fork/join for the two-stream backward: `side` (a second stream of the caller) and two events of the caller.
+struct SideStream {
+    hipStream_t stream = nullptr;
+    hipEvent_t fork = nullptr, join = nullptr;
+};
+
 static int deform_backward(const float *x, const float *weight, const float *offset, const float *mask,
                            const float *gout, const float *saved_cols, float *gx, float *goff, float *gmask,
-                           float *gw, float *gb, void *ws, size_t ws_bytes, const ddcn_geom *g, void *stream)
+                           float *gw, float *gb, void *ws, size_t ws_bytes, const ddcn_geom *g, void *stream,
+                           const SideStream *side = nullptr)
 {
     TRY(check_geom(g));
     TRY(check_ws(g, ws, ws_bytes));
     hipStream_t s = (hipStream_t)stream;
     float *col = (float *)ws;
+    if (saved_cols && ((uintptr_t)saved_cols & 15)) return fail(DDCN_ERR_BAD_ARG, "columns must be 16-byte aligned");
+    if (side && saved_cols) {
+        // G3 (+ G4) needs only grad_out and the saved columns: it runs on the side stream BESIDE the scatter, whose
+        // 2-channel variant is small enough to share each CU with the resident GEMM workgroup (the scatter is bound
+        // by LDS atomics, the GEMM by the matrix cores).  The caller's stream continues when both are done.
+        // The fork is recorded AFTER G2: two GEMMs side by side only share the matrix cores (measured: no gain), the
+        // point is G3 beside the scatter.
+        TRY(launch_gemm_gcol(weight, gout, col, *g, s));
+        hipError_t e = hipEventRecord(side->fork, s);
+        if (e == hipSuccess) e = hipStreamWaitEvent(side->stream, side->fork, 0);
+        if (e != hipSuccess) return fail(DDCN_ERR_LAUNCH, "two-stream backward: fork: %s", hipGetErrorString(e));
+        TRY(launch_gemm_gweight(gout, saved_cols, gw, *g, side->stream));
+        if (gb) TRY(launch_bias_grad(gout, gb, *g, side->stream));
+        TRY(launch_col2im_coord(col, x, offset, mask, gx, goff, gmask, *g, s, /*clear_coord=*/false, /*chunk_channels=*/2));
+        e = hipEventRecord(side->join, side->stream);
+        if (e == hipSuccess) e = hipStreamWaitEvent(s, side->join, 0);
+        if (e != hipSuccess) return fail(DDCN_ERR_LAUNCH, "two-stream backward: join: %s", hipGetErrorString(e));
+        return DDCN_OK;
+    }
     TRY(launch_gemm_gcol(weight, gout, col, *g, s));
     TRY(launch_col2im_coord(col, x, offset, mask, gx, goff, gmask, *g, s, /*clear_coord=*/false));
     if (saved_cols) {   // the forward call's columns are still there: no second im2col
-        if ((uintptr_t)saved_cols & 15) return fail(DDCN_ERR_BAD_ARG, "columns must be 16-byte aligned");
         TRY(launch_gemm_gweight(gout, saved_cols, gw, *g, s));
     } else {
         TRY(launch_im2col(x, offset, mask, col, *g, s));
@@ -325,6 +350,22 @@ int ddcn_modulated_deform_conv_backward_saved_f32(const float *x, const float *w
     REQUIRE(gx); REQUIRE(goff); REQUIRE(gmask); REQUIRE(gw);
     return deform_backward(x, weight, offset, mask, grad_out, columns, gx, goff, gmask, gw, gb, workspace,
                            workspace_bytes, g, stream);
+}
+
+int ddcn_deform_conv_backward_saved_2s_f32(const float *x, const float *weight, const float *offset,
+                                           const float *mask, const float *grad_out, const float *columns, float *gx,
+                                           float *goff, float *gmask, float *gw, float *gb, void *workspace,
+                                           size_t workspace_bytes, const ddcn_geom *g, void *stream, void *side_stream,
+                                           void *fork_event, void *join_event)
+{
+    REQUIRE(x); REQUIRE(weight); REQUIRE(offset); REQUIRE(grad_out); REQUIRE(columns);
+    REQUIRE(gx); REQUIRE(goff); REQUIRE(gw); REQUIRE(side_stream); REQUIRE(fork_event); REQUIRE(join_event);
+    if ((mask == nullptr) != (gmask == nullptr)) return fail(DDCN_ERR_BAD_ARG, "mask and gmask must both be given or both be NULL");
+    if (side_stream == stream) return fail(DDCN_ERR_BAD_ARG, "side_stream must differ from stream");
+    SideStream side;
+    side.stream = (hipStream_t)side_stream; side.fork = (hipEvent_t)fork_event; side.join = (hipEvent_t)join_event;
+    return deform_backward(x, weight, offset, mask, grad_out, columns, gx, goff, gmask, gw, gb, workspace,
+                           workspace_bytes, g, stream, &side);
 }
 
 int ddcn_depthaware_conv_forward_f32(const float *x, const float *depth, const float *weight, const float *bias,

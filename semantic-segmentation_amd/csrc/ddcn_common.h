@@ -60,9 +60,13 @@ int launch_skinny_gweight(const float *x, const float *offset, const float *gpre
 int launch_im2col_tiled(const float *x, const float *offset, const float *mask, float *col, const ddcn_geom &g,
                         hipStream_t stream, bool *handled);
 int launch_col2im_coord(const float *gcol, const float *x, const float *offset, const float *mask, float *gx,
-                        float *goff, float *gmask, const ddcn_geom &g, hipStream_t stream, bool clear_coord = true);
+                        float *goff, float *gmask, const ddcn_geom &g, hipStream_t stream, bool clear_coord = true,
+                        int chunk_channels = 0);
+// chunk_channels: 0 = default (4, or DDCN_SCATTER_SC); 2 = the variant small enough (<= 168 VGPRs, <= 40 KiB LDS) to
+// share a CU with a resident GEMM workgroup
 int launch_col2im_coord_tile9(const float *gcol, const float *x, const float *offset, const float *mask, float *gx,
-                              float *goff, float *gmask, const ddcn_geom &g, hipStream_t stream, bool *handled);
+                              float *goff, float *gmask, const ddcn_geom &g, hipStream_t stream, bool *handled,
+                              int chunk_channels = 0);
 int launch_col2im_coord_tiled(const float *gcol, const float *x, const float *offset, const float *mask, float *gx,
                               float *goff, float *gmask, const ddcn_geom &g, hipStream_t stream, bool *handled);
 int launch_depthaware_im2col(const float *x, const float *depth, float *col, const ddcn_geom &g,

@@ -319,7 +319,8 @@ int launch_im2col(const float *x, const float *offset, const float *mask, float 
 }
 
 int launch_col2im_coord(const float *gcol, const float *x, const float *offset, const float *mask, float *gx,
-                        float *goff, float *gmask, const ddcn_geom &g, hipStream_t stream, bool clear_coord)
+                        float *goff, float *gmask, const ddcn_geom &g, hipStream_t stream, bool clear_coord,
+                        int chunk_channels)
 {
     GatherArgs a = base_args(g);
     a.gcol = gcol; a.x = x; a.offset = offset; a.mask = mask; a.gx = gx; a.goff = goff; a.gmask = gmask;
@@ -331,7 +332,7 @@ int launch_col2im_coord(const float *gcol, const float *x, const float *offset, 
         e = hipMemsetAsync(gmask, 0, sizeof(float) * (size_t)g.N * g.dg * a.K2 * a.P, stream);
     if (e != hipSuccess) return fail(DDCN_ERR_LAUNCH, "col2im_coord: memset: %s", hipGetErrorString(e));
     bool handled = false;
-    int rc = launch_col2im_coord_tile9(gcol, x, offset, mask, gx, goff, gmask, g, stream, &handled);
+    int rc = launch_col2im_coord_tile9(gcol, x, offset, mask, gx, goff, gmask, g, stream, &handled, chunk_channels);
     if (handled || rc != DDCN_OK) return rc;
     rc = launch_col2im_coord_tiled(gcol, x, offset, mask, gx, goff, gmask, g, stream, &handled);
     if (handled || rc != DDCN_OK) return rc;

@@ -401,12 +401,14 @@ __global__ __launch_bounds__(ST, SC == 4 ? 2 : DDCN_S9_WPS) void col2im_coord_ti
 }
 
 int launch_col2im_coord_tile9(const float *gcol, const float *x, const float *offset, const float *mask, float *gx,
-                              float *goff, float *gmask, const ddcn_geom &g, hipStream_t stream, bool *handled)
+                              float *goff, float *gmask, const ddcn_geom &g, hipStream_t stream, bool *handled,
+                              int chunk_channels)
 {
     *handled = false;
     const Dims d = dims_of(g);
     if (g.kh != 3 || g.kw != 3) return DDCN_OK;
-    static const int SC = getenv("DDCN_SCATTER_SC") ? atoi(getenv("DDCN_SCATTER_SC")) : 4;
+    static const int env_sc = getenv("DDCN_SCATTER_SC") ? atoi(getenv("DDCN_SCATTER_SC")) : 4;
+    const int SC = chunk_channels > 0 ? chunk_channels : env_sc;
     if (SC != 2 && SC != 4) return DDCN_OK;
     if (g.H >= 32766 || g.W >= 32766 || d.cpg % SC) return DDCN_OK;
     if ((long)g.C * d.K2 * d.ld * 4 >= (1L << 31) || (long)g.C * g.H * g.W * 4 >= (1L << 31)) return DDCN_OK;

@@ -59,6 +59,7 @@ PROTOTYPES = {
     "ddcn_modulated_deform_conv_backward_f32": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _SZ, _G, _P],
     "ddcn_deform_conv_backward_saved_f32": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _SZ, _G, _P],
     "ddcn_modulated_deform_conv_backward_saved_f32": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _SZ, _G, _P],
+    "ddcn_deform_conv_backward_saved_2s_f32": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _SZ, _G, _P, _P, _P, _P],
     "ddcn_depthaware_conv_forward_f32": [_P, _P, _P, _P, _P, _P, _SZ, _G, _P],
     "ddcn_depthaware_conv_backward_f32": [_P, _P, _P, _P, _P, _P, _P, _P, _SZ, _G, _P],
     "ddcn_workspace_bytes_f64": [_G],

@@ -14,8 +14,8 @@ Deliberate deviations from the reference:
   C5  kernels run on torch's current stream, not the legacy default stream.
   C6  the columns scratch is torch.empty (never zero-filled) and comes from the caching allocator.
 """
+import ctypes
 import math
-
 import os
 
 import torch
@@ -92,6 +92,50 @@ SAVE_COLUMNS = os.environ.get("DDCN_SAVE_COLUMNS", "1") != "0"
 # columns, MFMA with fp32 accumulation (BASELINE config 5).  DDCN_BF16_NATIVE=0, a geometry they do not cover, or any tensor that
 # requires grad selects the fp32 kernels (convert in, compute, convert out).
 BF16_NATIVE = os.environ.get("DDCN_BF16_NATIVE", "1") != "0"
+
+
+# Saved-columns fp32 backward on two streams (ddcn_deform_conv_backward_saved_2s_f32): the weight-gradient GEMM runs on
+# a side stream beside the LDS-atomic-bound scatter.  DDCN_TWO_STREAM_BACKWARD=0 keeps everything on one stream.
+TWO_STREAM_BACKWARD = os.environ.get("DDCN_TWO_STREAM_BACKWARD", "1") != "0"
+_side = {}
+
+
+def _side_stream(device):
+    """(side stream, fork event, join event) of a device, created once; the events are recorded once so that their
+    HIP handles exist before the library is handed them."""
+    key = (device.type, device.index if device.index is not None else torch.cuda.current_device())
+    if key not in _side:
+        with torch.cuda.device(device):
+            stream = torch.cuda.Stream()
+            fork, join = torch.cuda.Event(), torch.cuda.Event()
+            fork.record(stream)
+            join.record(stream)
+        _side[key] = (stream, fork, join)
+    return _side[key]
+
+
+def _backward_saved(cd, input, weight, offset, mask, grad_output, cols, grad_input, grad_offset, grad_mask, grad_weight,
+                    grad_bias, ws, ws_bytes, g):
+    """One saved-columns backward call (mask / grad_mask None: the non-modulated op) on input's device."""
+    p = _lib.ptr
+    stream = torch.cuda.current_stream(input.device)
+    if (TWO_STREAM_BACKWARD and cols is not None and cd == torch.float32
+            and not torch.cuda.is_current_stream_capturing()):
+        side, fork, join = _side_stream(input.device)
+        _lib.check(_lib.lib().ddcn_deform_conv_backward_saved_2s_f32(
+            p(input), p(weight), p(offset), p(mask), p(grad_output), p(cols), p(grad_input), p(grad_offset),
+            p(grad_mask), p(grad_weight), p(grad_bias), p(ws), ws_bytes, g, ctypes.c_void_p(stream.cuda_stream),
+            ctypes.c_void_p(side.cuda_stream), ctypes.c_void_p(fork.cuda_event), ctypes.c_void_p(join.cuda_event)))
+        return
+    s = ctypes.c_void_p(stream.cuda_stream)
+    if mask is None:
+        _lib.check(_entry("ddcn_deform_conv_backward_saved", cd)(
+            p(input), p(weight), p(offset), p(grad_output), p(cols), p(grad_input), p(grad_offset), p(grad_weight),
+            p(grad_bias), p(ws), ws_bytes, g, s))
+    else:
+        _lib.check(_entry("ddcn_modulated_deform_conv_backward_saved", cd)(
+            p(input), p(weight), p(offset), p(mask), p(grad_output), p(cols), p(grad_input), p(grad_offset),
+            p(grad_mask), p(grad_weight), p(grad_bias), p(ws), ws_bytes, g, s))
 
 
 def _bf16_forward(input, offset, mask, weight, bias, g):
@@ -215,11 +259,8 @@ class DeformConvFunction(Function):
         ws, ws_bytes = _workspace(input, g, cd)
         with torch.cuda.device(input.device):
             cols, ctx.columns = getattr(ctx, "columns", None), None
-            _lib.check(_entry("ddcn_deform_conv_backward_saved", cd)(
-                _lib.ptr(input), _lib.ptr(weight), _lib.ptr(offset), _lib.ptr(grad_output),
-                _lib.ptr(cols) if cols is not None else None, _lib.ptr(grad_input),
-                _lib.ptr(grad_offset), _lib.ptr(grad_weight), _lib.ptr(grad_bias) if ctx.with_bias else None,
-                _lib.ptr(ws), ws_bytes, g, _lib.current_stream(input.device)))
+            _backward_saved(cd, input, weight, offset, None, grad_output, cols, grad_input, grad_offset, None,
+                            grad_weight, grad_bias if ctx.with_bias else None, ws, ws_bytes, g)
         if not ctx.with_bias:
             grad_bias = None
         if ctx.dtype != cd:
@@ -300,11 +341,8 @@ class ModulatedDeformConvFunction(Function):
         ws, ws_bytes = _workspace(input, g, cd)
         with torch.cuda.device(input.device):
             cols, ctx.columns = getattr(ctx, "columns", None), None
-            _lib.check(_entry("ddcn_modulated_deform_conv_backward_saved", cd)(
-                _lib.ptr(input), _lib.ptr(weight), _lib.ptr(offset), _lib.ptr(mask), _lib.ptr(grad_output),
-                _lib.ptr(cols) if cols is not None else None, _lib.ptr(grad_input), _lib.ptr(grad_offset), _lib.ptr(grad_mask), _lib.ptr(grad_weight),
-                _lib.ptr(grad_bias) if ctx.with_bias else None, _lib.ptr(ws), ws_bytes, g,
-                _lib.current_stream(input.device)))
+            _backward_saved(cd, input, weight, offset, mask, grad_output, cols, grad_input, grad_offset, grad_mask,
+                            grad_weight, grad_bias if ctx.with_bias else None, ws, ws_bytes, g)
         if not ctx.with_bias:
             grad_bias = None
         if ctx.dtype != cd:

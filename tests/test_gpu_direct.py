@@ -101,3 +101,65 @@ def test_direct_backward_full_size_mask_branch_against_oracle():
     assert cases.relerr(gx.cpu().numpy(), egx) <= BWD_TOL
     assert cases.relerr(goff.cpu().numpy(), egoff) <= BWD_TOL
     assert cases.relerr(gw.cpu().numpy(), egw) <= BWD_TOL
+
+
+@pytest.mark.parametrize("modulated", [True, False], ids=["modulated", "plain"])
+def test_two_stream_saved_backward_matches_single_stream_and_oracle(modulated):
+    """ddcn_deform_conv_backward_saved_2s_f32 (G3 on a side stream beside the scatter) against the oracle and against
+    the one-stream entry point on the same saved columns."""
+    L = _lib.lib()
+    c = cases.C("two_stream", N=2, Ci=64, Co=48, H=33, W=29, pad=2, dil=2, bias=True, modulated=modulated, seed=60)
+    inp = {k: (None if v is None else v.astype(np.float32).astype(np.float64)) for k, v in cases.make_inputs(c).items()}
+    Ho, Wo, _ = cases.geometry(c)
+    g = _lib.Geom(c["N"], c["Ci"], c["H"], c["W"], c["Co"], 3, 3, 1, 1, 2, 2, 2, 2, 1, 1, Ho, Wo)
+    x, w, off, gout, b = (_dev(inp[k]) for k in ("x", "weight", "offset", "gout", "bias"))
+    m = _dev(inp["mask"]) if modulated else None
+    nbytes = L.ddcn_workspace_bytes(g)
+    cols, ws = torch.empty(nbytes // 4, device=DEV), torch.empty(nbytes // 4, device=DEV)
+    out = torch.empty(c["N"], c["Co"], Ho, Wo, device=DEV)
+    main = torch.cuda.current_stream()
+    sm = _lib.current_stream(torch.device(DEV))
+    if modulated:
+        _lib.check(L.ddcn_modulated_deform_conv_forward_f32(_lib.ptr(x), _lib.ptr(w), _lib.ptr(b), _lib.ptr(off),
+                                                            _lib.ptr(m), _lib.ptr(out), _lib.ptr(cols), nbytes, g, sm))
+    else:
+        _lib.check(L.ddcn_deform_conv_forward_f32(_lib.ptr(x), _lib.ptr(w), _lib.ptr(b), _lib.ptr(off), _lib.ptr(out),
+                                                  _lib.ptr(cols), nbytes, g, sm))
+    side = torch.cuda.Stream()
+    fork, join = torch.cuda.Event(), torch.cuda.Event()
+    fork.record(side); join.record(side)
+    import ctypes
+    res = []
+    for two in (True, False):
+        gx, goff, gw = torch.zeros_like(x), torch.zeros_like(off), torch.zeros_like(w)
+        gm = torch.zeros_like(m) if modulated else None
+        gb = torch.zeros(c["Co"], device=DEV)
+        if two:
+            _lib.check(L.ddcn_deform_conv_backward_saved_2s_f32(
+                _lib.ptr(x), _lib.ptr(w), _lib.ptr(off), _lib.ptr(m), _lib.ptr(gout), _lib.ptr(cols), _lib.ptr(gx),
+                _lib.ptr(goff), _lib.ptr(gm), _lib.ptr(gw), _lib.ptr(gb), _lib.ptr(ws), nbytes, g,
+                ctypes.c_void_p(main.cuda_stream), ctypes.c_void_p(side.cuda_stream), ctypes.c_void_p(fork.cuda_event),
+                ctypes.c_void_p(join.cuda_event)))
+        elif modulated:
+            _lib.check(L.ddcn_modulated_deform_conv_backward_saved_f32(
+                _lib.ptr(x), _lib.ptr(w), _lib.ptr(off), _lib.ptr(m), _lib.ptr(gout), _lib.ptr(cols), _lib.ptr(gx),
+                _lib.ptr(goff), _lib.ptr(gm), _lib.ptr(gw), _lib.ptr(gb), _lib.ptr(ws), nbytes, g, sm))
+        else:
+            _lib.check(L.ddcn_deform_conv_backward_saved_f32(
+                _lib.ptr(x), _lib.ptr(w), _lib.ptr(off), _lib.ptr(gout), _lib.ptr(cols), _lib.ptr(gx), _lib.ptr(goff),
+                _lib.ptr(gw), _lib.ptr(gb), _lib.ptr(ws), nbytes, g, sm))
+        main.synchronize()       # the call joined the side stream into `main`: this alone must cover G3
+        res.append([t.cpu().numpy() for t in (gx, goff, gw, gb)] + [gm.cpu().numpy() if modulated else None])
+    egx, egoff, egmask, egw, egb = orc.deform_backward(inp["x"], inp["offset"], inp["mask"] if modulated else None,
+                                                       inp["weight"], inp["gout"], True, **cases.kwargs(c))
+    for got in res:
+        for a, e in zip(got[:4], (egx, egoff, egw, egb)):
+            assert cases.relerr(a, e) <= BWD_TOL
+        if modulated:
+            assert cases.relerr(got[4], egmask) <= BWD_TOL
+    # same side stream == main stream is refused
+    rc = L.ddcn_deform_conv_backward_saved_2s_f32(
+        _lib.ptr(x), _lib.ptr(w), _lib.ptr(off), _lib.ptr(m), _lib.ptr(gout), _lib.ptr(cols), _lib.ptr(x), _lib.ptr(off),
+        _lib.ptr(m), _lib.ptr(w), None, _lib.ptr(ws), nbytes, g, ctypes.c_void_p(side.cuda_stream),
+        ctypes.c_void_p(side.cuda_stream), ctypes.c_void_p(fork.cuda_event), ctypes.c_void_p(join.cuda_event))
+    assert rc == -1
