@@ -15,7 +15,11 @@
  *     `columns` tensor inside every call (H:214-216, H:292-293);
  *   - every function returns 0 (DDCN_OK) or a negative DDCN_ERR_* code and never throws;
  *     ddcn_strerror() names the code, ddcn_last_error() gives the detail for the calling thread;
- *   - the library keeps no state between calls and is re-entrant.
+ *   - what the library keeps between calls: a per-device flag per kernel that its dynamic-LDS limit has been raised
+ *     (hipFuncSetAttribute, once per device), tuning knobs read from the environment at first use (DDCN_*), the
+ *     last-error text per thread, and the per-device address of the static scratch of the *_static_f32 entry point.
+ *     No call touches another call's data: concurrent calls from several threads / streams are safe (the *_static_f32
+ *     entry point excepted, see there).
  *
  * Tensor shapes (K2 = kh*kw, P = Ho*Wo):
  *   x[N,C,H,W]  weight[Co,C/groups,kh,kw]  bias[Co]  offset[N,dg*2*K2,Ho,Wo]  (channel 2k = dh, 2k+1 = dw)
@@ -227,7 +231,7 @@ int ddcn_depthaware_conv_backward_f64(const double *x, const double *depth, cons
  * No counterpart in the reference (it dispatches fp64/fp32/fp16 only, K:258): BASELINE config 5, "bf16 activations with
  * fp32 accumulation".  Every tensor pointer is bfloat16 (torch.bfloat16 data_ptr()): x, weight, bias, offset, mask,
  * out; coordinates and bilinear weights are computed in fp32, samples are rounded to bf16 columns, the contraction
- * accumulates in fp32 on v_mfma_f32_32x32x16_bf16 and the result (+ bias) is rounded to bf16 once.  Arithmetic
+ * accumulates in fp32 on v_mfma_f32_16x16x32_bf16 (32x32x16 in the register-staged fallback) and the result (+ bias) is rounded to bf16 once.  Arithmetic
  * restated: K:569-632 / K:189-242 (im2col) and H:430-435 / H:232-237 (GEMM).  mask == NULL gives the non-modulated
  * op, bias may be NULL.  Covered: 3x3 kernels with C, C/groups and C/deformable_groups multiples of 8
  * (ddcn_bf16_supported() == 0); workspace of ddcn_workspace_bytes_bf16() bytes (the bf16 columns of all N images). */
