@@ -121,9 +121,11 @@ int ddcn_deform_conv_direct_forward_f32(const float *x, const float *weight, con
                                         float *out, int sigmoid, void *workspace, size_t workspace_bytes,
                                         const ddcn_geom *g, void *stream);
 /* The backward of the direct forward above (same coverage; anything else behaves like ddcn_deform_conv_backward_f32):
- * gx, goff as H:299-323, but the weight gradient (H:325-346: a second im2col into the columns tensor, then a Co-row
- * GEMM) is formed by ONE kernel that samples x again and multiplies the samples into Co x 9 accumulators per input
- * channel -- no columns are written or read for it.  grad_out is the gradient w.r.t. the PRE-activation value (the
+ * NO columns at all.  gx / goff (H:299-323: a Co-row GEMM into the columns tensor, then col2im and col2im_coord) come
+ * from the fused scatter kernel in a mode that forms each column gradient, a Co-term dot product of the repacked
+ * weights with the pixel's Co output gradients, right before it scatters it; the weight gradient (H:325-346: a second
+ * im2col, then a Co-row GEMM) from ONE kernel that samples x again and multiplies the samples into Co x 9
+ * accumulators per input channel.  grad_out is the gradient w.r.t. the PRE-activation value (the
  * caller applies the sigmoid derivative).  ACCUMULATES into gx, goff, gw, gb like the other backward entry points. */
 int ddcn_deform_conv_direct_backward_f32(const float *x, const float *weight, const float *offset,
                                          const float *grad_out, float *gx, float *goff, float *gw, float *gb,

@@ -289,10 +289,15 @@ int ddcn_deform_conv_direct_backward_f32(const float *x, const float *weight, co
     TRY(check_ws(g, workspace, workspace_bytes));
     hipStream_t s = (hipStream_t)stream;
     float *col = (float *)workspace;
-    TRY(launch_gemm_gcol(weight, grad_out, col, *g, s));
-    TRY(launch_col2im_coord(col, x, offset, nullptr, gx, goff, nullptr, *g, s, /*clear_coord=*/false));
     bool handled = false;
-    // no second im2col, no 9-row G3 (the column gradients in the workspace are dead now: it takes the sample table)
+    // grad_input / grad_offset straight from grad_out: the 9-term W^T * grad_out is formed inside the scatter kernel
+    TRY(launch_skinny_scatter(x, offset, weight, grad_out, gx, goff, workspace, workspace_bytes, *g, s, &handled));
+    if (!handled) {
+        TRY(launch_gemm_gcol(weight, grad_out, col, *g, s));
+        TRY(launch_col2im_coord(col, x, offset, nullptr, gx, goff, nullptr, *g, s, /*clear_coord=*/false));
+    }
+    handled = false;
+    // no second im2col, no 9-row G3 (the workspace is free again: it takes the sample table)
     TRY(launch_skinny_gweight(x, offset, grad_out, gw, workspace, workspace_bytes, *g, s, &handled));
     if (!handled) {
         TRY(launch_im2col(x, offset, nullptr, col, *g, s));

@@ -66,7 +66,9 @@ int launch_col2im_coord(const float *gcol, const float *x, const float *offset, 
 // share a CU with a resident GEMM workgroup
 int launch_col2im_coord_tile9(const float *gcol, const float *x, const float *offset, const float *mask, float *gx,
                               float *goff, float *gmask, const ddcn_geom &g, hipStream_t stream, bool *handled,
-                              int chunk_channels = 0);
+                              int chunk_channels = 0, const float *sk_w = nullptr, const float *sk_g = nullptr);
+int launch_skinny_scatter(const float *x, const float *offset, const float *weight, const float *gout, float *gx,
+                          float *goff, void *ws, size_t ws_bytes, const ddcn_geom &g, hipStream_t stream, bool *handled);
 int launch_col2im_coord_tiled(const float *gcol, const float *x, const float *offset, const float *mask, float *gx,
                               float *goff, float *gmask, const ddcn_geom &g, hipStream_t stream, bool *handled);
 int launch_depthaware_im2col(const float *x, const float *depth, float *col, const ddcn_geom &g,

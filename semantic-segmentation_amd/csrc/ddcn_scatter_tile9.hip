@@ -41,7 +41,13 @@ struct Tile9Args {
     int TH, TW, tiles_w, tiles, groups;
     int CG, M;
     int RH, RW, RS;
+    // SKB mode (few output channels, no column gradients in memory): gcol[c,k,p] = sum_o sk_w[c][k][o] * sk_g[n][o][p]
+    const float *sk_w;   // weights repacked [C][9][SKB] (zero beyond sk_co)
+    const float *sk_g;   // gradient w.r.t. the convolution output [N][sk_co][P]
+    int sk_co;
 };
+
+constexpr int SKB_MAX = 12;
 
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t s9_rsrc(const void *base, long bytes)
 {
@@ -57,10 +63,16 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t s9_rsrc(const void *base, long
 // number is exact for both fields (the borrow of a negative low part is undone when the word is decoded as
 // lo = int32(word), hi = (word - lo) >> 32).  Resolution: 2^-19 of the chunk's largest column value per add.
 // A non-finite column value cannot be represented: the chunk then writes NaN to every cell it could have touched.
-template <bool MOD, int NCELL, int SC, bool FX>
+// SKB > 0: the column gradients are never in memory.  For a deformable convolution with few (<= SKB) output channels
+// -- the DDCN layer's 9-channel mask branch -- gcol = W^T * grad_out is a 9-term dot product per element: each lane keeps
+// its pixel's SKB output gradients in registers, the chunk's weights ([4 channels][9 taps][SKB], repacked by the host
+// side) are staged in LDS next to the patch and read as broadcast ds_read_b128, and a tap's four column values are
+// formed right before they are scattered (the reference: a 9-row GEMM into an 86.7 MB columns tensor, H:305-308).
+template <bool MOD, int NCELL, int SC, bool FX, int SKB = 0>
 __global__ __launch_bounds__(ST, SC == 4 ? 2 : DDCN_S9_WPS) void col2im_coord_tile9_kernel(Tile9Args a)
 {
     static_assert(!FX || SC == 4, "fixed-point footprint packs channel pairs of a 4-channel chunk");
+    static_assert(SKB == 0 || (SC == 4 && !FX && !MOD && SKB % 4 == 0), "direct mode: plain op, 4-channel chunks");
     typedef float xvec __attribute__((ext_vector_type(SC)));
     typedef unsigned long long u64;
     constexpr int K2 = 9;
@@ -70,6 +82,7 @@ __global__ __launch_bounds__(ST, SC == 4 ? 2 : DDCN_S9_WPS) void col2im_coord_ti
     double *gs = reinterpret_cast<double *>(smem_raw);                       // [SC][RS]: a wave's 64 cells -> 128 banks
     u64 *gq = reinterpret_cast<u64 *>(smem_raw);                             // FX: [SC/2][RS], channels (2j, 2j+1)
     xvec *xs = reinterpret_cast<xvec *>(smem_raw + (size_t)a.RS * SC * GB);   // [RS][SC]
+    float *wl = reinterpret_cast<float *>(smem_raw + (size_t)a.RS * SC * (GB + 4));   // SKB: [SC][9][SKB] weights of the chunk
     const ddcn_geom &g = a.g;
     const int t = threadIdx.x;
 
@@ -92,7 +105,7 @@ __global__ __launch_bounds__(ST, SC == 4 ? 2 : DDCN_S9_WPS) void col2im_coord_ti
     const int p = live ? ho * g.Wo + wo : 0;
 
     const __amdgpu_buffer_rsrc_t rx = s9_rsrc(a.x + (long)n * g.C * HW, (long)g.C * HW * 4);
-    const __amdgpu_buffer_rsrc_t rgc = s9_rsrc(a.gcol + (long)n * g.C * K2 * a.ld, (long)g.C * K2 * a.ld * 4);
+    const __amdgpu_buffer_rsrc_t rgc = s9_rsrc(a.gcol + (long)n * g.C * K2 * a.ld, SKB ? 0 : (long)g.C * K2 * a.ld * 4);
     float *gxn = a.gx + (long)n * g.C * HW;
 
     // patch cell i = t + 256*j -> byte offset inside one channel plane (out of image: rejected by the descriptor)
@@ -168,6 +181,45 @@ __global__ __launch_bounds__(ST, SC == 4 ? 2 : DDCN_S9_WPS) void col2im_coord_ti
         }
     };
 
+    constexpr int WCH = SKB ? SC * K2 * SKB : 1;              // weights per chunk
+    constexpr int WPT = SKB ? (WCH + ST - 1) / ST : 1;        // ... per thread
+    float wreg[WPT];
+    float gp[SKB ? SKB : 1];
+    auto wstage_load = [&](int c0) {
+        if (SKB) {
+#pragma unroll
+            for (int r = 0; r < WPT; ++r) {
+                const int i = t + ST * r;
+                wreg[r] = i < WCH ? a.sk_w[(long)c0 * K2 * SKB + i] : 0.f;
+            }
+        }
+    };
+    auto wstage_store = [&]() {
+        if (SKB) {
+#pragma unroll
+            for (int r = 0; r < WPT; ++r)
+                if (t + ST * r < WCH) wl[t + ST * r] = wreg[r];
+        }
+    };
+    if (SKB) {
+#pragma unroll
+        for (int o = 0; o < (SKB ? SKB : 1); ++o)
+            gp[o] = (live && o < a.sk_co) ? a.sk_g[((long)n * a.sk_co + o) * a.P + p] : 0.f;
+    }
+    // column value (channel cc of the chunk, tap k) in direct mode
+    auto sk_col = [&](int k, int cc) -> float {
+        float v = 0.f;
+        if (SKB) {
+            const f32x4 *wv = reinterpret_cast<const f32x4 *>(wl + (cc * K2 + k) * SKB);
+#pragma unroll
+            for (int q4 = 0; q4 < SKB / 4; ++q4) {
+                const f32x4 w4 = wv[q4];
+                v += w4.x * gp[4 * q4] + w4.y * gp[4 * q4 + 1] + w4.z * gp[4 * q4 + 2] + w4.w * gp[4 * q4 + 3];
+            }
+        }
+        return v;
+    };
+
     if (FX) {
         for (int i = t; i < a.RS * SC / 2; i += ST) gq[i] = 0ull;
         if (t < 2) s_max[t] = 0u;
@@ -175,9 +227,11 @@ __global__ __launch_bounds__(ST, SC == 4 ? 2 : DDCN_S9_WPS) void col2im_coord_ti
         for (int i = t; i < a.RS * SC; i += ST) gs[i] = 0.0;
     }
     stage_load(cg0);
+    wstage_load(cg0);
     stage_store();
+    wstage_store();
 
-    const unsigned pvo = live ? (unsigned)(p * 4) : SOOB;
+    const unsigned pvo = (live && !SKB) ? (unsigned)(p * 4) : SOOB;   // direct mode: every column load is rejected
     const int nchunks = a.CG / SC;
     // column values of the current chunk; each tap reloads its registers for the next chunk as soon as it is done
     float gcv[K2][SC];
@@ -219,7 +273,7 @@ __global__ __launch_bounds__(ST, SC == 4 ? 2 : DDCN_S9_WPS) void col2im_coord_ti
             (void)frexpf(fx_bad ? 1.f : gmax, &fx_e);                     // gmax < 2^fx_e (gmax == 0: nothing is added)
         }
         // A. the next patch goes in flight
-        if (more) stage_load(c0 + SC);
+        if (more) { stage_load(c0 + SC); wstage_load(c0 + SC); }
         __builtin_amdgcn_sched_barrier(0);
 
         // B. taps: gather x, accumulate the S sums, scatter into the LDS footprint
@@ -260,7 +314,7 @@ __global__ __launch_bounds__(ST, SC == 4 ? 2 : DDCN_S9_WPS) void col2im_coord_ti
                     double *c1 = gs + ci, *c3 = gs + ci + a.RW;
 #pragma unroll
                     for (int cc = 0; cc < SC; ++cc) {
-                        const float gc = gcv[k][cc];
+                        const float gc = SKB ? sk_col(k, cc) : gcv[k][cc];
                         S1[k] += gc * a1[cc]; S2[k] += gc * a2[cc]; S3[k] += gc * a3[cc]; S4[k] += gc * a4[cc];
                         const float tg = MOD ? gc * fm[k] : gc;
                         atomicAdd(c1 + cc * a.RS, (double)(w1 * tg));
@@ -270,10 +324,12 @@ __global__ __launch_bounds__(ST, SC == 4 ? 2 : DDCN_S9_WPS) void col2im_coord_ti
                     }
                 }
             }
+            if (!SKB) {
 #pragma unroll
-            for (int cc = 0; cc < SC; ++cc)
-                gcv[k][cc] = __builtin_bit_cast(
-                    float, __builtin_amdgcn_raw_buffer_load_b32(rgc, pvn, (unsigned)(((c0 + SC + cc) * K2 + k) * a.ld * 4), 0));
+                for (int cc = 0; cc < SC; ++cc)
+                    gcv[k][cc] = __builtin_bit_cast(
+                        float, __builtin_amdgcn_raw_buffer_load_b32(rgc, pvn, (unsigned)(((c0 + SC + cc) * K2 + k) * a.ld * 4), 0));
+            }
             __builtin_amdgcn_sched_barrier(0);
         }
         if (FX && more) publish_max((ch + 1) & 1);   // gcv now holds the next chunk
@@ -331,7 +387,7 @@ __global__ __launch_bounds__(ST, SC == 4 ? 2 : DDCN_S9_WPS) void col2im_coord_ti
                 }
             }
         }
-        if (more) stage_store();
+        if (more) { stage_store(); wstage_store(); }
         __syncthreads();
     }
 
@@ -360,7 +416,15 @@ __global__ __launch_bounds__(ST, SC == 4 ? 2 : DDCN_S9_WPS) void col2im_coord_ti
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
                     const int c = min(c0 + u, a.CG - 1);
-                    gc[u] = gcp[(long)c * K2 * a.ld];
+                    if (SKB) {
+                        const float *wr = a.sk_w + ((long)(cg0 + c) * K2 + k) * SKB;
+                        float v = 0.f;
+#pragma unroll
+                        for (int o = 0; o < (SKB ? SKB : 1); ++o) v += wr[o] * gp[o];
+                        gc[u] = v;
+                    } else {
+                        gc[u] = gcp[(long)c * K2 * a.ld];
+                    }
                     r1[u] = im[(long)c * HW + o1]; r2[u] = im[(long)c * HW + o2];
                     r3[u] = im[(long)c * HW + o3]; r4[u] = im[(long)c * HW + o4];
                 }
@@ -400,11 +464,41 @@ __global__ __launch_bounds__(ST, SC == 4 ? 2 : DDCN_S9_WPS) void col2im_coord_ti
     }
 }
 
-int launch_col2im_coord_tile9(const float *gcol, const float *x, const float *offset, const float *mask, float *gx,
-                              float *goff, float *gmask, const ddcn_geom &g, hipStream_t stream, bool *handled,
-                              int chunk_channels)
+// weight[Co][C][9] -> wp[C][9][SKB_MAX] (zero beyond Co): the 9 x SKB block of a channel is contiguous for the LDS staging
+__global__ __launch_bounds__(256) void repack_skinny_w_kernel(const float *w, float *wp, int Co, int C)
+{
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (long)C * 9 * SKB_MAX) return;
+    const int o = (int)(i % SKB_MAX);
+    const long ck = i / SKB_MAX;
+    wp[i] = o < Co ? w[(long)o * C * 9 + ck] : 0.f;
+}
+
+// Direct backward scatter for few output channels: grad_input / grad_offset straight from grad_out (no column
+// gradients in memory).  `ws` receives the repacked weights (C * 9 * 12 floats).  *handled = false: not covered.
+int launch_skinny_scatter(const float *x, const float *offset, const float *weight, const float *gout, float *gx,
+                          float *goff, void *ws, size_t ws_bytes, const ddcn_geom &g, hipStream_t stream, bool *handled)
 {
     *handled = false;
+    static const int env_on = getenv("DDCN_SKINNY_SCATTER") ? atoi(getenv("DDCN_SKINNY_SCATTER")) : 1;
+    const size_t need = (size_t)g.C * 9 * SKB_MAX * sizeof(float);
+    if (!env_on || g.kh != 3 || g.kw != 3 || g.Co > SKB_MAX || g.groups != 1 || g.dg != 1 || ws_bytes < need) return DDCN_OK;
+    // plan first (nothing is launched when the tile kernel does not cover the geometry)
+    float *wp = (float *)ws;
+    const long total = (long)g.C * 9 * SKB_MAX;
+    hipLaunchKernelGGL(repack_skinny_w_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, weight, wp, g.Co, g.C);
+    if (int rc = check_launch("repack_skinny_w")) return rc;
+    return launch_col2im_coord_tile9(nullptr, x, offset, nullptr, gx, goff, nullptr, g, stream, handled, 4, wp, gout);
+}
+
+int launch_col2im_coord_tile9(const float *gcol, const float *x, const float *offset, const float *mask, float *gx,
+                              float *goff, float *gmask, const ddcn_geom &g, hipStream_t stream, bool *handled,
+                              int chunk_channels, const float *sk_w, const float *sk_g)
+{
+    *handled = false;
+    const bool direct = sk_w != nullptr;
+    if (direct && (mask || g.Co > SKB_MAX || g.groups != 1 || g.dg != 1 || !sk_g)) return DDCN_OK;
+    if (direct) chunk_channels = 4;
     const Dims d = dims_of(g);
     if (g.kh != 3 || g.kw != 3) return DDCN_OK;
     static const int env_sc = getenv("DDCN_SCATTER_SC") ? atoi(getenv("DDCN_SCATTER_SC")) : 4;
@@ -437,7 +531,8 @@ int launch_col2im_coord_tile9(const float *gcol, const float *x, const float *of
     for (int M = env_m; M >= 0 && !ok; M -= 2) {
         const int RH = (TH - 1) * g.sh + 2 * g.dh + 2 + 2 * M;
         const int RW = (TW - 1) * g.sw + 2 * g.dw + 2 + 2 * M;
-        if (RH * RW <= SMAXCELLS * ST && (size_t)RH * RW * 12 * SC <= (size_t)(SC == 4 ? S9_LDS_MAX : S9_LDS_MAX / 2)) {
+        const size_t wbytes = direct ? (size_t)4 * 9 * SKB_MAX * sizeof(float) : 0;
+        if (RH * RW <= SMAXCELLS * ST && (size_t)RH * RW * 12 * SC + wbytes <= (size_t)(SC == 4 ? S9_LDS_MAX : S9_LDS_MAX / 2)) {
             a.M = M; a.RH = RH; a.RW = RW; a.RS = RH * RW;
             ok = true;
         }
@@ -451,13 +546,14 @@ int launch_col2im_coord_tile9(const float *gcol, const float *x, const float *of
     *handled = true;
     a.gcol = gcol; a.x = x; a.offset = offset; a.mask = mask; a.gx = gx; a.goff = goff; a.gmask = gmask;
     a.g = g; a.P = d.P; a.cpg = d.cpg; a.ld = d.ld;
+    a.sk_w = sk_w; a.sk_g = sk_g; a.sk_co = g.Co;
     const long nwg = (long)a.tiles * a.groups;
     if (nwg > 0x7fffffffL || g.N > 65535) return fail(DDCN_ERR_UNSUPPORTED, "col2im_coord_tile9: grid too large");
     dim3 grid((unsigned)nwg, 1, g.N);
     // opt-in (read per call so that tests can switch it): 15-25 % faster, grad_input accurate to ~1e-5 instead of ~1e-7
     const char *env_fx = getenv("DDCN_SCATTER_FX");
-    const bool fx = env_fx && atoi(env_fx) != 0 && SC == 4;
-    const size_t smem = (size_t)a.RS * (fx ? 8 : 12) * SC;
+    const bool fx = env_fx && atoi(env_fx) != 0 && SC == 4 && !direct;
+    const size_t smem = (size_t)a.RS * (fx ? 8 : 12) * SC + (direct ? (size_t)4 * 9 * SKB_MAX * sizeof(float) : 0);
     const int ncell = (a.RS + ST - 1) / ST;
     bool ok_lds = true;
     // each instantiation's dynamic-LDS limit is raised once per device to the planner's cap (80 KiB), not per call
@@ -477,10 +573,23 @@ int launch_col2im_coord_tile9(const float *gcol, const float *x, const float *of
         else if (SC == 4) DDCN_S9_LAUNCH2(false, NC, 4, false);                                                  \
         else DDCN_S9_LAUNCH2(false, NC, 2, false);                                                               \
     } while (0)
-    if (ncell <= 2) DDCN_S9_LAUNCH(2);
+#define DDCN_S9_LAUNCH_DIRECT(NC)                                                                                \
+    do {                                                                                                         \
+        static std::atomic<uint64_t> raised{0};                                                                  \
+        ok_lds = raise_lds_limit((const void *)&col2im_coord_tile9_kernel<false, NC, 4, false, SKB_MAX>, S9_LDS_MAX, raised); \
+        if (ok_lds)                                                                                              \
+            hipLaunchKernelGGL((col2im_coord_tile9_kernel<false, NC, 4, false, SKB_MAX>), grid, dim3(ST), smem, stream, a); \
+    } while (0)
+    if (direct) {
+        if (ncell <= 2) DDCN_S9_LAUNCH_DIRECT(2);
+        else if (ncell <= 4) DDCN_S9_LAUNCH_DIRECT(4);
+        else if (ncell <= 6) DDCN_S9_LAUNCH_DIRECT(6);
+        else DDCN_S9_LAUNCH_DIRECT(8);
+    } else if (ncell <= 2) DDCN_S9_LAUNCH(2);
     else if (ncell <= 4) DDCN_S9_LAUNCH(4);
     else if (ncell <= 6) DDCN_S9_LAUNCH(6);
     else DDCN_S9_LAUNCH(8);
+#undef DDCN_S9_LAUNCH_DIRECT
 #undef DDCN_S9_LAUNCH2
 #undef DDCN_S9_LAUNCH
     if (!ok_lds) return fail(DDCN_ERR_LAUNCH, "col2im_coord_tile9: cannot raise the dynamic LDS limit to %d bytes", S9_LDS_MAX);
