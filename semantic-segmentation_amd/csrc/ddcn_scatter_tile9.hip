@@ -68,9 +68,17 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t s9_rsrc(const void *base, long
 // its pixel's SKB output gradients in registers, the chunk's weights ([4 channels][9 taps][SKB], repacked by the host
 // side) are staged in LDS next to the patch and read as broadcast ds_read_b128, and a tap's four column values are
 // formed right before they are scattered (the reference: a 9-row GEMM into an 86.7 MB columns tensor, H:305-308).
-template <bool MOD, int NCELL, int SC, bool FX, int SKB = 0>
+// XQ: the footprint as EXACT 64-bit fixed point, one channel per word, accumulated with ds_add_u64 (19 cycles per wave
+// instruction against 23-24 for ds_add_f64).  Scale per chunk and workgroup 2^(50 - e) with gmax < 2^e as for FX: a
+// contribution is below 2^50, 2304 of them below 2^62.  A float times a power of two is exact in double, and
+// fma(v, scale, 1.5 * 2^52) leaves round(v * scale) in the low mantissa bits (|v * scale| < 2^51), so the only rounding is
+// to 2^-50 of the chunk's largest value -- 2^-26 of an fp32 ulp of it.  Integer sums do not depend on the order of the
+// adds: the LDS part of the scatter is deterministic in this mode.
+template <bool MOD, int NCELL, int SC, bool FX, int SKB = 0, bool XQ = false>
 __global__ __launch_bounds__(ST, SC == 4 ? 2 : DDCN_S9_WPS) void col2im_coord_tile9_kernel(Tile9Args a)
 {
+    static_assert(!XQ || (!FX && SKB == 0), "exact fixed point: its own mode");
+    constexpr bool MAXQ = FX || XQ;        // modes that need the chunk's largest |value|
     static_assert(!FX || SC == 4, "fixed-point footprint packs channel pairs of a 4-channel chunk");
     static_assert(SKB == 0 || (SC == 4 && !FX && !MOD && SKB % 4 == 0), "direct mode: plain op, 4-channel chunks");
     typedef float xvec __attribute__((ext_vector_type(SC)));
@@ -223,6 +231,9 @@ __global__ __launch_bounds__(ST, SC == 4 ? 2 : DDCN_S9_WPS) void col2im_coord_ti
     if (FX) {
         for (int i = t; i < a.RS * SC / 2; i += ST) gq[i] = 0ull;
         if (t < 2) s_max[t] = 0u;
+    } else if (XQ) {
+        for (int i = t; i < a.RS * SC; i += ST) gq[i] = 0ull;
+        if (t < 2) s_max[t] = 0u;
     } else {
         for (int i = t; i < a.RS * SC; i += ST) gs[i] = 0.0;
     }
@@ -256,7 +267,7 @@ __global__ __launch_bounds__(ST, SC == 4 ? 2 : DDCN_S9_WPS) void col2im_coord_ti
         // non-negative floats (and +inf, NaN) order like their bit patterns
         if (m != 0.f) atomicMax(&s_max[parity], __float_as_uint(m) & 0x7fffffffu);
     };
-    if (FX) {
+    if (MAXQ) {
         __syncthreads();            // s_max is zero before anyone publishes
         publish_max(0);
     }
@@ -267,11 +278,12 @@ __global__ __launch_bounds__(ST, SC == 4 ? 2 : DDCN_S9_WPS) void col2im_coord_ti
         const unsigned pvn = more ? pvo : SOOB;
         int fx_e = 0;               // FX: contributions are scaled by 2^(19 - fx_e)
         bool fx_bad = false;
-        if (FX) {
+        if (MAXQ) {
             const float gmax = __uint_as_float(s_max[ch & 1]);
             fx_bad = !(gmax <= 3.0e38f);                                  // inf or NaN in the chunk
             (void)frexpf(fx_bad ? 1.f : gmax, &fx_e);                     // gmax < 2^fx_e (gmax == 0: nothing is added)
         }
+        const double xq_scale = XQ ? __builtin_ldexp(1.0, 50 - fx_e) : 0.0;
         // A. the next patch goes in flight
         if (more) { stage_load(c0 + SC); wstage_load(c0 + SC); }
         __builtin_amdgcn_sched_barrier(0);
@@ -310,6 +322,24 @@ __global__ __launch_bounds__(ST, SC == 4 ? 2 : DDCN_S9_WPS) void col2im_coord_ti
                             atomicAdd(q3 + pr * a.RS + 1, pack(w4 * lo, w4 * hi));
                         }
                     }
+                } else if (XQ) {
+                    u64 *q1 = gq + ci, *q3 = gq + ci + a.RW;
+                    auto fixed = [&](float v) -> u64 {
+                        const double r = __builtin_fma((double)v, xq_scale, 6755399441055744.0);   // + 1.5 * 2^52
+                        return __builtin_bit_cast(u64, r) - 0x4338000000000000ull;
+                    };
+#pragma unroll
+                    for (int cc = 0; cc < SC; ++cc) {
+                        const float gc = gcv[k][cc];
+                        S1[k] += gc * a1[cc]; S2[k] += gc * a2[cc]; S3[k] += gc * a3[cc]; S4[k] += gc * a4[cc];
+                        const float tg = MOD ? gc * fm[k] : gc;
+                        if (!fx_bad) {
+                            atomicAdd(q1 + cc * a.RS, fixed(w1 * tg));
+                            atomicAdd(q1 + cc * a.RS + 1, fixed(w2 * tg));
+                            atomicAdd(q3 + cc * a.RS, fixed(w3 * tg));
+                            atomicAdd(q3 + cc * a.RS + 1, fixed(w4 * tg));
+                        }
+                    }
                 } else {
                     double *c1 = gs + ci, *c3 = gs + ci + a.RW;
 #pragma unroll
@@ -332,7 +362,7 @@ __global__ __launch_bounds__(ST, SC == 4 ? 2 : DDCN_S9_WPS) void col2im_coord_ti
             }
             __builtin_amdgcn_sched_barrier(0);
         }
-        if (FX && more) publish_max((ch + 1) & 1);   // gcv now holds the next chunk
+        if (MAXQ && more) publish_max((ch + 1) & 1);   // gcv now holds the next chunk
         __syncthreads();
 
         // C. flush the footprint (one global atomic per touched in-image cell), re-zero, install the next patch
@@ -362,6 +392,30 @@ __global__ __launch_bounds__(ST, SC == 4 ? 2 : DDCN_S9_WPS) void col2im_coord_ti
                                     if (lo != 0) atomicAdd(dst + (2 * pr) * HW, (float)lo * inv);
                                     if (hi != 0) atomicAdd(dst + (2 * pr + 1) * HW, (float)hi * inv);
                                 }
+                            }
+                        }
+                    }
+                }
+            }
+        } else if (XQ) {
+            if (t == 0) s_max[ch & 1] = 0u;
+            const double inv = __builtin_ldexp(1.0, fx_e - 50);
+#pragma unroll
+            for (int j = 0; j < NCELL; ++j) {
+                const int i = t + ST * j;
+                if (i < a.RS) {
+                    u64 wq[SC];
+                    bool any = fx_bad;
+#pragma unroll
+                    for (int cc = 0; cc < SC; ++cc) { wq[cc] = gq[i + cc * a.RS]; any |= wq[cc] != 0ull; }
+                    if (any) {
+                        float *dst = gxn + (long)c0 * HW + (soff[j] >> 2);
+#pragma unroll
+                        for (int cc = 0; cc < SC; ++cc) {
+                            gq[i + cc * a.RS] = 0ull;
+                            if (soff[j] != SOOB) {
+                                if (fx_bad) atomicAdd(dst + cc * HW, __uint_as_float(0x7fc00000u));
+                                else if (wq[cc] != 0ull) atomicAdd(dst + cc * HW, (float)((double)(long long)wq[cc] * inv));
                             }
                         }
                     }
@@ -553,6 +607,8 @@ int launch_col2im_coord_tile9(const float *gcol, const float *x, const float *of
     // opt-in (read per call so that tests can switch it): 15-25 % faster, grad_input accurate to ~1e-5 instead of ~1e-7
     const char *env_fx = getenv("DDCN_SCATTER_FX");
     const bool fx = env_fx && atoi(env_fx) != 0 && SC == 4 && !direct;
+    const char *env_xq = getenv("DDCN_SCATTER_XQ");
+    const bool xq = !fx && !direct && !(env_xq && atoi(env_xq) == 0);   // default; DDCN_SCATTER_XQ=0: double footprint
     const size_t smem = (size_t)a.RS * (fx ? 8 : 12) * SC + (direct ? (size_t)4 * 9 * SKB_MAX * sizeof(float) : 0);
     const int ncell = (a.RS + ST - 1) / ST;
     bool ok_lds = true;
@@ -564,9 +620,23 @@ int launch_col2im_coord_tile9(const float *gcol, const float *x, const float *of
         if (ok_lds)                                                                                              \
             hipLaunchKernelGGL((col2im_coord_tile9_kernel<MOD, NC, SCV, FXV>), grid, dim3(ST), smem, stream, a); \
     } while (0)
+#define DDCN_S9_LAUNCH_XQ2(MOD, NC, SCV)                                                                         \
+    do {                                                                                                         \
+        static std::atomic<uint64_t> raised{0};                                                                  \
+        ok_lds = raise_lds_limit((const void *)&col2im_coord_tile9_kernel<MOD, NC, SCV, false, 0, true>, S9_LDS_MAX, raised); \
+        if (ok_lds)                                                                                              \
+            hipLaunchKernelGGL((col2im_coord_tile9_kernel<MOD, NC, SCV, false, 0, true>), grid, dim3(ST), smem, stream, a); \
+    } while (0)
+#define DDCN_S9_LAUNCH_XQ(MOD, NC)                                                                               \
+    do {                                                                                                         \
+        if (SC == 4) DDCN_S9_LAUNCH_XQ2(MOD, NC, 4);                                                             \
+        else DDCN_S9_LAUNCH_XQ2(MOD, NC, 2);                                                                     \
+    } while (0)
 #define DDCN_S9_LAUNCH(NC)                                                                                       \
     do {                                                                                                         \
-        if (mask && fx) DDCN_S9_LAUNCH2(true, NC, 4, true);                                                      \
+        if (xq && mask) DDCN_S9_LAUNCH_XQ(true, NC);                                                             \
+        else if (xq) DDCN_S9_LAUNCH_XQ(false, NC);                                                               \
+        else if (mask && fx) DDCN_S9_LAUNCH2(true, NC, 4, true);                                                 \
         else if (fx) DDCN_S9_LAUNCH2(false, NC, 4, true);                                                        \
         else if (mask && SC == 4) DDCN_S9_LAUNCH2(true, NC, 4, false);                                           \
         else if (mask) DDCN_S9_LAUNCH2(true, NC, 2, false);                                                      \
