@@ -40,6 +40,7 @@ struct GemmArgs {
     long nA, nB, nC;          // elements of one (z0, z1) slice of A / B / C (descriptor bounds)
     int nz1, ksplit, kchunk;  // nz = nz0 * nz1 * ksplit slices ; kchunk multiple of BK
     int tiles_m;
+    int stream_out;           // 1: C is written once and read much later (column gradients): non-temporal stores
     int nb, nn;               // column tiles per slice: nb of width BN, then nn of width BN_TAIL
     int total_big, total_nar;    // tiles_m * nb * nz wide tiles, tiles_m * nn * nz narrow tiles
     int blocks_big, blocks_nar;  // workgroups per class: two tiles (one per wave group) each
@@ -319,7 +320,8 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs &a, float *smem, int gr
                     const float v = acc[i][j][e] + bias[i][e];
                     const bool ok = (m0 + ml < a.M) && (n0 + nl < a.N);
                     const unsigned voff = ok ? (unsigned)(((long)ml * a.ldc + nl) * 4) : OOB;
-                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rc, voff, 0, 0);
+                    if (a.stream_out) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rc, voff, 0, 2);
+                    else __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rc, voff, 0, 0);
                 }
             }
     }
@@ -451,6 +453,8 @@ int launch_gemm_gcol(const float *weight, const float *gout, float *gcol, const 
     a.sC0 = (long)d.Ktot * d.ld; a.sC1 = (long)d.Kg * d.ld;
     a.nA = a.sA1; a.nB = a.sB1; a.nC = a.sC1;
     a.nz1 = g.groups; a.ksplit = 1; a.kchunk = (int)round_up(d.Cog, BK);
+    static const int env_nt = getenv("DDCN_GEMM_NT") ? atoi(getenv("DDCN_GEMM_NT")) : 0;
+    a.stream_out = env_nt;    // opt-in: measured slower (0.704 vs 0.692 ms), see DDCN_IM2COL_STORE_AUX
     return launch<false, false, false>(a, g.N, stream, "gemm_gcol");
 }
 

@@ -28,6 +28,13 @@ namespace ddcn {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int IT = 256;
+#ifndef DDCN_IM2COL_STORE_AUX
+// Cache-policy bits of the column stores (bit 1 = non-temporal / streaming).  Measured at config 1 (profiles/r02b_*):
+// with nt the kernel alone drops from 0.120 to 0.086 ms (56 % of HBM; sc0 / sc1 change nothing), but the columns then
+// miss the Infinity Cache when G1 reads them back and G1 goes from 0.677 to 0.752 ms: the step is 0.025 ms SLOWER.  The
+// default stays write-allocate; the same holds for the column gradients G2 writes (DDCN_GEMM_NT).
+#define DDCN_IM2COL_STORE_AUX 0
+#endif
 constexpr int CC = 4;          // channels per LDS chunk (one ds_read_b128 per corner)
 constexpr int MAXCELLS = 12;    // staging registers: patch cells per thread (patch <= 8 * 256 cells), template NCELL
 constexpr unsigned OOBV = 0x80000000u;
@@ -240,7 +247,7 @@ __global__ __launch_bounds__(IT, 2) void im2col_tile_kernel(Im2colTileArgs a)
                             }
                         } else {
                             __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, val), rcol, pvo,
-                                                                  rowk + cc * rstep, 0);
+                                                                  rowk + cc * rstep, DDCN_IM2COL_STORE_AUX);
                         }
                     }
                 }
@@ -288,7 +295,7 @@ __global__ __launch_bounds__(IT, 2) void im2col_tile_kernel(Im2colTileArgs a)
                                     if (co < a.sk_co) sacc[co] += a.sk_w[((long)co * g.C + cg0 + c) * K2 + k] * val;
                             } else {
                                 __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, val), rcol, pvo,
-                                                                      (unsigned)(((cg0 + c) * K2 + k) * a.ld * 4), 0);
+                                                                      (unsigned)(((cg0 + c) * K2 + k) * a.ld * 4), DDCN_IM2COL_STORE_AUX);
                             }
                         }
                     }
@@ -589,7 +596,7 @@ __global__ __launch_bounds__(IT, 2) void skinny_gweight_kernel(SkinnyGwArgs a)
         float clh[K2], clw[K2], cgp[COMAX];
 #pragma unroll
         for (int k = 0; k < K2; ++k) {
-            chw[k] = live ? __float_as_int(tl[k]) : (TAB_INVALID << 16);
+            chw[k] = live ? __float_as_int(tl[k]) : (int)((unsigned)TAB_INVALID << 16);
             clh[k] = th[k]; clw[k] = tw[k];
         }
 #pragma unroll

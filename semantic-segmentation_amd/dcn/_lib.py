@@ -10,7 +10,8 @@ import os
 import torch  # noqa: F401  (imported first so that the library binds to torch's HIP runtime)
 
 _PKG = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-LIB_PATH = os.path.join(_PKG, "lib", "libddcn_hip.so")
+# DDCN_LIB_PATH: another build of the same library (kernel experiments); the default is the in-tree build
+LIB_PATH = os.environ.get("DDCN_LIB_PATH") or os.path.join(_PKG, "lib", "libddcn_hip.so")
 
 
 class Geom(ctypes.Structure):
