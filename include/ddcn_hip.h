@@ -250,6 +250,19 @@ int ddcn_modulated_deform_conv_forward_f16(const void *x, const void *weight, co
                                            const void *mask, void *out, void *workspace, size_t workspace_bytes,
                                            const ddcn_geom *g, void *stream);
 
+/* G2 of the backward on 16-bit operands (the reference's half instantiation of H:305-308 / H:503-506): weight and grad_out
+ * are bfloat16 / float16 tensors, the column gradients gcol[N][C*K2][ld] come out in fp32 (fp32 accumulation on
+ * v_mfma_f32_16x16x32_{bf16,f16}), ready for ddcn_col2im_coord_f32.  `workspace` (ddcn_gemm_gcol_16_workspace_bytes)
+ * takes the repacked operands.  Covered: Co/groups a multiple of 8 (ddcn_gemm_gcol_16_supported() == 0); any kernel
+ * size.  Used by the autograd functions for half / bfloat16 training: forward on the native 16-bit kernels, G2 here,
+ * scatter / im2col / G3 on the fp32 kernels (a 16-bit G3 needs the columns in pixel octets: DESIGN.md section 8). */
+size_t ddcn_gemm_gcol_16_workspace_bytes(const ddcn_geom *g);
+int ddcn_gemm_gcol_16_supported(const ddcn_geom *g);
+int ddcn_gemm_gcol_bf16(const void *weight, const void *grad_out, float *gcol, void *workspace, size_t workspace_bytes,
+                        const ddcn_geom *g, void *stream);
+int ddcn_gemm_gcol_f16(const void *weight, const void *grad_out, float *gcol, void *workspace, size_t workspace_bytes,
+                       const ddcn_geom *g, void *stream);
+
 /* ---------------------------------------------------------------- deformable PS-RoI pooling
  * Replaces the reference's second extension, `detseg.ops.dcn.deform_pool_cuda`:
  *   PP = detseg/ops/dcn/deform_pool.py

@@ -560,6 +560,45 @@ int ddcn_modulated_deform_conv_forward_f16(const void *x, const void *weight, co
     return launch_forward_f16(x, weight, bias, offset, mask, out, workspace, *g, (hipStream_t)stream);
 }
 
+// ---------------------------------------------------------------- 16-bit backward: G2 on 16-bit operands
+size_t ddcn_gemm_gcol_16_workspace_bytes(const ddcn_geom *g)
+{
+    if (check_geom(g) != DDCN_OK || gcol16_supported(*g) != DDCN_OK) return 0;
+    return gcol16_workspace_bytes(*g);
+}
+
+int ddcn_gemm_gcol_16_supported(const ddcn_geom *g)
+{
+    TRY(check_geom(g));
+    return gcol16_supported(*g);
+}
+
+static int gemm_gcol_16(bool bf16, const void *weight, const void *grad_out, float *gcol, void *ws, size_t ws_bytes,
+                        const ddcn_geom *g, void *stream)
+{
+    REQUIRE(weight); REQUIRE(grad_out); REQUIRE(gcol);
+    TRY(check_geom(g));
+    TRY(gcol16_supported(*g));
+    if (!ws || ws_bytes < gcol16_workspace_bytes(*g) || ((uintptr_t)ws & 15))
+        return fail(DDCN_ERR_WORKSPACE, "16-bit G2 workspace of %zu bytes (16-byte aligned), need %zu", ws_bytes,
+                    gcol16_workspace_bytes(*g));
+    if ((uintptr_t)gcol & 15) return fail(DDCN_ERR_BAD_ARG, "gcol must be 16-byte aligned");
+    return bf16 ? launch_gemm_gcol_bf16(weight, grad_out, gcol, ws, *g, (hipStream_t)stream)
+                : launch_gemm_gcol_f16(weight, grad_out, gcol, ws, *g, (hipStream_t)stream);
+}
+
+int ddcn_gemm_gcol_bf16(const void *weight, const void *grad_out, float *gcol, void *workspace, size_t workspace_bytes,
+                        const ddcn_geom *g, void *stream)
+{
+    return gemm_gcol_16(true, weight, grad_out, gcol, workspace, workspace_bytes, g, stream);
+}
+
+int ddcn_gemm_gcol_f16(const void *weight, const void *grad_out, float *gcol, void *workspace, size_t workspace_bytes,
+                       const ddcn_geom *g, void *stream)
+{
+    return gemm_gcol_16(false, weight, grad_out, gcol, workspace, workspace_bytes, g, stream);
+}
+
 int ddcn_deform_psroi_pool_forward_f32(const float *data, const float *rois, const float *offset, float *out,
                                        float *out_count, const ddcn_roi_geom *g, void *stream)
 {

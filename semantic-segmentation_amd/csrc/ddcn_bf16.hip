@@ -99,6 +99,8 @@ struct Bf16Args {
     // LDS-tiled im2col
     int M, RH, RW, RS, CG, tiles, tiles_w;
     int pair, rw_shift;   // pair staging: patch starts rw_shift columns further left so that it starts on an even column
+    float *outf;          // GEMM result as fp32 rows of ldc floats (the column gradients of the 16-bit backward) instead of `out`
+    long ldc;
 };
 
 constexpr int IT = 256;  // im2col threads
@@ -711,7 +713,10 @@ void gemm16_dma_kernel(const Bf16Args a)
             for (int j = 0; j < 4; ++j) {
                 const int col = n0 + wn * 64 + j * 16 + r16;
                 const float v = acc[i][j][e] + bv;
-                if (col < a.P) C[(long)row * a.P + col] = (bf16_t)T::pack2(v, 0.f);
+                if (col < a.P) {
+                    if (a.outf) a.outf[((long)img * a.Co + (long)grp * M + row) * a.ldc + col] = v;
+                    else C[(long)row * a.P + col] = (bf16_t)T::pack2(v, 0.f);
+                }
             }
         }
     }
@@ -879,6 +884,111 @@ int launch_forward_f16(const void *x, const void *weight, const void *bias, cons
                        void *out, void *ws, const ddcn_geom &g, hipStream_t stream)
 {
     return forward_16<F16>(x, weight, bias, offset, mask, out, ws, g, stream);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// G2 of the 16-bit backward: gcol[n][g] (Kg x ld, fp32) = W[g]^T * grad_out[n][g] with 16-bit operands and fp32
+// accumulation on the LDS-DMA GEMM above (the reference's half instantiation runs this product in half, H:305-308 /
+// H:503-506 under AT_DISPATCH_FLOATING_TYPES_AND_HALF).  A = W^T in the blocked layout [group][Cog/32][Kg][32]
+// (zero-padded in k), B = grad_out as channel octets [n][Co/8][P][8]; both are written into `ws` by two small kernels.
+namespace {
+
+// wp[((grp * KT + kt) * M + m) * 32 + k32] = W[(grp * Cog + kt*32 + k32) * M + m]   (M = Kg = C/groups * kh * kw)
+__global__ __launch_bounds__(256) void repack_wT_blocked_kernel(const bf16_t *w, bf16_t *wp, long total, int Cog, int M)
+{
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int KT = (Cog + 31) / 32;
+    const int k32 = (int)(i & 31);
+    const long rest = i >> 5;
+    const int m = (int)(rest % M);
+    const long gk = rest / M;
+    const int kt = (int)(gk % KT);
+    const long grp = gk / KT;
+    const int k = kt * 32 + k32;
+    wp[i] = k < Cog ? w[(grp * Cog + k) * (long)M + m] : (bf16_t)0;
+}
+
+// go[((n * Co/8 + o8) * P + p) * 8 + e] = gout[(n * Co + o8*8 + e) * P + p]; one thread per (n, o8, p)
+__global__ __launch_bounds__(256) void repack_gout_octets_kernel(const bf16_t *gout, u32x4 *go, int Co, int P)
+{
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    if (p >= P) return;
+    const int o8 = blockIdx.y, n = blockIdx.z;
+    const bf16_t *src = gout + ((long)n * Co + o8 * 8) * P + p;
+    unsigned short v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = src[(long)e * P];
+    u32x4 o;
+    o.x = v[0] | ((unsigned)v[1] << 16); o.y = v[2] | ((unsigned)v[3] << 16);
+    o.z = v[4] | ((unsigned)v[5] << 16); o.w = v[6] | ((unsigned)v[7] << 16);
+    go[((long)n * (Co / 8) + o8) * P + p] = o;
+}
+
+}  // namespace
+
+size_t gcol16_workspace_bytes(const ddcn_geom &g)
+{
+    const size_t Cog = g.Co / g.groups, M = (size_t)(g.C / g.groups) * g.kh * g.kw, KT = (Cog + 31) / 32;
+    return round_up((size_t)g.groups * KT * M * 32 * 2, 256) + (size_t)g.N * g.Co * g.Ho * g.Wo * 2;
+}
+
+int gcol16_supported(const ddcn_geom &g)
+{
+    const long P = (long)g.Ho * g.Wo, Cog = g.Co / g.groups, M = (long)(g.C / g.groups) * g.kh * g.kw;
+    if (Cog % 8) return fail(DDCN_ERR_UNSUPPORTED, "16-bit G2: Co/groups must be a multiple of 8 (Co=%d groups=%d)", g.Co, g.groups);
+    const long kpad = (Cog + 31) / 32 * 32;
+    if (M * kpad * 2 >= (1L << 31) || (Cog / 8) * P * 16 >= (1L << 31) || P >= (1L << 31) / 16 ||
+        (long)g.N * g.groups > 65535 || g.Co / 8 > 65535 || g.N > 65535)
+        return fail(DDCN_ERR_UNSUPPORTED, "16-bit G2: tensor too large");
+    return DDCN_OK;
+}
+
+template <typename T>
+static int gemm_gcol_16(const void *weight, const void *gout, float *gcol, void *ws, const ddcn_geom &g, hipStream_t stream)
+{
+    if (int rc = gcol16_supported(g)) return rc;
+    const Dims d = dims_of(g);
+    const int Cog = d.Cog, M = d.Kg, P = d.P, KT = (Cog + 31) / 32;   // M = C/groups * kh * kw: any kernel size
+    bf16_t *wp = (bf16_t *)ws;
+    u32x4 *go = (u32x4 *)((char *)ws + round_up((size_t)g.groups * KT * M * 32 * 2, 256));
+    const long wtotal = (long)g.groups * KT * M * 32;
+    hipLaunchKernelGGL(repack_wT_blocked_kernel, dim3((unsigned)((wtotal + 255) / 256)), dim3(256), 0, stream,
+                       (const bf16_t *)weight, wp, wtotal, Cog, M);
+    hipLaunchKernelGGL(repack_gout_octets_kernel, dim3((unsigned)((P + 255) / 256), (unsigned)(g.Co / 8), (unsigned)g.N),
+                       dim3(256), 0, stream, (const bf16_t *)gout, go, g.Co, P);
+    if (int rc = check_launch("repack_16")) return rc;
+    Bf16Args a = {};
+    a.weight = wp; a.col = (bf16_t *)go; a.bias = nullptr; a.out = nullptr;
+    a.outf = gcol; a.ldc = d.ld;
+    a.N = g.N; a.P = P; a.groups = g.groups;
+    a.Co = g.groups * M;          // rows of one image's result (the kernel's `Co`: the C * kh * kw column rows)
+    a.Cog = M;                    // rows per group
+    a.Kg = Cog;                   // reduction length per group
+    a.KO = g.Co / 8;              // k-octets of one image of B
+    // tile class as in the forward: 256x256 tiles when they fill the chip, else 128x128 (4 stages)
+    const long tiles_sq = (long)((M + 255) / 256) * ((P + 255) / 256) * g.N * g.groups;
+    if (M >= 192 && tiles_sq >= 256) {
+        const dim3 g8((unsigned)((M + 255) / 256 * ((P + 255) / 256)), (unsigned)(g.N * g.groups));
+        static std::atomic<uint64_t> raised{0};
+        if (!raise_lds_limit((const void *)gemm16_dma_kernel<T, 4, 4, 4>, 4 * 32768, raised))
+            return fail(DDCN_ERR_LAUNCH, "gemm_gcol_16: cannot raise the LDS limit");
+        hipLaunchKernelGGL((gemm16_dma_kernel<T, 4, 4, 4>), g8, dim3(512), 4 * 32768, stream, a);
+    } else {
+        const dim3 gg((unsigned)((M + 127) / 128 * ((P + 127) / 128)), (unsigned)(g.N * g.groups));
+        hipLaunchKernelGGL((gemm16_dma_kernel<T, 4, 2>), gg, dim3(GT), 4 * 16384, stream, a);
+    }
+    return check_launch("gemm_gcol_16");
+}
+
+int launch_gemm_gcol_bf16(const void *weight, const void *gout, float *gcol, void *ws, const ddcn_geom &g, hipStream_t stream)
+{
+    return gemm_gcol_16<BF16>(weight, gout, gcol, ws, g, stream);
+}
+
+int launch_gemm_gcol_f16(const void *weight, const void *gout, float *gcol, void *ws, const ddcn_geom &g, hipStream_t stream)
+{
+    return gemm_gcol_16<F16>(weight, gout, gcol, ws, g, stream);
 }
 
 }  // namespace ddcn

@@ -78,6 +78,10 @@ PROTOTYPES = {
     "ddcn_bf16_supported": [_G],
     "ddcn_modulated_deform_conv_forward_bf16": [_P, _P, _P, _P, _P, _P, _P, _SZ, _G, _P],
     "ddcn_modulated_deform_conv_forward_f16": [_P, _P, _P, _P, _P, _P, _P, _SZ, _G, _P],
+    "ddcn_gemm_gcol_16_workspace_bytes": [_G],
+    "ddcn_gemm_gcol_16_supported": [_G],
+    "ddcn_gemm_gcol_bf16": [_P, _P, _P, _P, _SZ, _G, _P],
+    "ddcn_gemm_gcol_f16": [_P, _P, _P, _P, _SZ, _G, _P],
     "ddcn_deform_psroi_pool_forward_f32": [_P, _P, _P, _P, _P, _RG, _P],
     "ddcn_deform_psroi_pool_backward_f32": [_P, _P, _P, _P, _P, _P, _P, _RG, _P],
     "ddcn_deform_psroi_pool_forward_f64": [_P, _P, _P, _P, _P, _RG, _P],
@@ -90,6 +94,7 @@ _RESTYPES = {
     "ddcn_workspace_bytes": _SZ,
     "ddcn_static_scratch_bytes": _SZ,
     "ddcn_workspace_bytes_bf16": _SZ,
+    "ddcn_gemm_gcol_16_workspace_bytes": _SZ,
     "ddcn_workspace_bytes_f64": _SZ,
 }
 

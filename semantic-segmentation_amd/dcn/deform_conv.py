@@ -138,6 +138,45 @@ def _backward_saved(cd, input, weight, offset, mask, grad_output, cols, grad_inp
             p(grad_mask), p(grad_weight), p(grad_bias), p(ws), ws_bytes, g, s))
 
 
+# Training on bfloat16 / float16 tensors: forward on the native 16-bit kernels (16-bit columns, not kept), backward with
+# G2 on the 16-bit operands (ddcn_gemm_gcol_{bf16,f16}) and the scatter / im2col / G3 on the fp32 kernels.
+# DDCN_16BIT_TRAIN_NATIVE=0: everything on the fp32 kernels (convert in, compute, convert out), as in round 1.
+TRAIN16_NATIVE = os.environ.get("DDCN_16BIT_TRAIN_NATIVE", "1") != "0"
+
+
+def _backward_16bit(dtype, input, offset, mask, weight, grad_output, with_bias, g):
+    """(grad_input, grad_offset, grad_mask | None, grad_weight, grad_bias | None) in `dtype`, or None when the 16-bit
+    G2 does not cover the geometry.  All tensors are 16-bit; mask None = the non-modulated op."""
+    L = _lib.lib()
+    if not TRAIN16_NATIVE or L.ddcn_gemm_gcol_16_supported(g) != 0:
+        return None
+    p = _lib.ptr
+    grad_output = grad_output.contiguous()
+    x32, off32, gout32 = input.float(), offset.float(), grad_output.float()
+    mask32 = None if mask is None else mask.float()
+    acts = [x32, off32] + ([mask32] if mask is not None else [])
+    grads = _zeros_flat(acts)
+    gx, goff = grads[0], grads[1]
+    gmask = grads[2] if mask is not None else None
+    gw = torch.zeros(weight.shape, dtype=torch.float32, device=input.device)
+    gb = torch.zeros(g.Co, dtype=torch.float32, device=input.device) if with_bias else None
+    ws_bytes = L.ddcn_workspace_bytes(g)
+    ws = torch.empty(ws_bytes // 4, dtype=torch.float32, device=input.device)
+    ws16_bytes = L.ddcn_gemm_gcol_16_workspace_bytes(g)
+    ws16 = torch.empty(ws16_bytes // 2, dtype=dtype, device=input.device)
+    gemm = L.ddcn_gemm_gcol_bf16 if dtype == torch.bfloat16 else L.ddcn_gemm_gcol_f16
+    with torch.cuda.device(input.device):
+        s = _lib.current_stream(input.device)
+        _lib.check(gemm(p(weight), p(grad_output), p(ws), p(ws16), ws16_bytes, g, s))               # G2, 16-bit operands
+        _lib.check(L.ddcn_col2im_coord_f32(p(ws), p(x32), p(off32), p(mask32), p(gx), p(goff), p(gmask), g, s))
+        _lib.check(L.ddcn_im2col_f32(p(x32), p(off32), p(mask32), p(ws), g, s))                       # columns for G3
+        _lib.check(L.ddcn_gemm_gweight_f32(p(gout32), p(ws), p(gw), g, s))
+        if with_bias:
+            _lib.check(L.ddcn_bias_grad_f32(p(gout32), p(gb), g, s))
+    cv = lambda t: None if t is None else t.to(dtype)
+    return cv(gx), cv(goff), cv(gmask), cv(gw), cv(gb)
+
+
 def _bf16_forward(input, offset, mask, weight, bias, g):
     """-> output, or None when the native bf16 path does not cover this call."""
     L = _lib.lib()
@@ -230,9 +269,10 @@ class DeformConvFunction(Function):
         needs_grad = weight.requires_grad or offset.requires_grad or input.requires_grad
         if needs_grad:
             ctx.save_for_backward(input, offset, weight, bias)
-        elif ctx.dtype in (torch.bfloat16, torch.float16):
+        if ctx.dtype in (torch.bfloat16, torch.float16) and (not needs_grad or TRAIN16_NATIVE):
             output = _bf16_forward(input, offset, None, weight, bias if ctx.with_bias else None, g)
             if output is not None:
+                ctx.columns = None
                 return output
         input, offset, weight, bias = (_cast(t, cd) for t in (input, offset, weight, bias))
         output = input.new_empty(
@@ -251,6 +291,14 @@ class DeformConvFunction(Function):
         if not grad_output.is_cuda:
             raise NotImplementedError
         cd = _cdtype(ctx.dtype)
+        if ctx.dtype in (torch.bfloat16, torch.float16):
+            input, offset, weight, bias = ctx.saved_tensors
+            g = _geom(input, weight, ctx.stride, ctx.padding, ctx.dilation, ctx.groups, ctx.deformable_groups)
+            _expect_shape("grad_output", grad_output, (g.N, g.Co, g.Ho, g.Wo))
+            res = _backward_16bit(ctx.dtype, input, offset, None, weight, grad_output, ctx.with_bias, g)
+            if res is not None:
+                ctx.columns = None
+                return (res[0], res[1], res[3], res[4], None, None, None, None, None)
         input, offset, weight, bias = (_cast(t, cd) for t in ctx.saved_tensors)
         grad_output = _cast(grad_output.contiguous(), cd)
         grad_input, grad_offset, grad_weight, grad_bias = _zeros_like_all(input, offset, weight, bias)
@@ -312,9 +360,10 @@ class ModulatedDeformConvFunction(Function):
         needs_grad = weight.requires_grad or mask.requires_grad or offset.requires_grad or input.requires_grad
         if needs_grad:
             ctx.save_for_backward(input, offset, mask, weight, bias)
-        elif ctx.dtype in (torch.bfloat16, torch.float16):
+        if ctx.dtype in (torch.bfloat16, torch.float16) and (not needs_grad or TRAIN16_NATIVE):
             output = _bf16_forward(input, offset, mask, weight, bias if ctx.with_bias else None, g)
             if output is not None:
+                ctx.columns = None
                 return output
         input, offset, mask, weight, bias = (_cast(t, cd) for t in (input, offset, mask, weight, bias))
         output = input.new_empty(
@@ -333,6 +382,14 @@ class ModulatedDeformConvFunction(Function):
         if not grad_output.is_cuda:
             raise NotImplementedError
         cd = _cdtype(ctx.dtype)
+        if ctx.dtype in (torch.bfloat16, torch.float16):
+            input, offset, mask, weight, bias = ctx.saved_tensors
+            g = _geom(input, weight, ctx.stride, ctx.padding, ctx.dilation, ctx.groups, ctx.deformable_groups)
+            _expect_shape("grad_output", grad_output, (g.N, g.Co, g.Ho, g.Wo))
+            res = _backward_16bit(ctx.dtype, input, offset, mask, weight, grad_output, ctx.with_bias, g)
+            if res is not None:
+                ctx.columns = None
+                return res + (None, None, None, None, None)
         input, offset, mask, weight, bias = (_cast(t, cd) for t in ctx.saved_tensors)
         grad_output = _cast(grad_output.contiguous(), cd)
         grad_input, grad_offset, grad_mask, grad_weight, grad_bias = _zeros_like_all(input, offset, mask, weight, bias)

@@ -57,6 +57,20 @@ def test_infer_output_matches_reference_formula(H, W, k, s, p, d):
     assert _lib.lib().ddcn_workspace_bytes(g) == 4 * 1 * 4 * k * k * ld
 
 
+@pytest.mark.parametrize("k", [1, 3, 5])
+def test_16bit_g2_workspace_follows_the_kernel_size(k):
+    """The 16-bit G2 writes C/groups * kh * kw rows per group: its operand workspace (blocked W^T + grad_out octets)
+    and the columns buffer it fills must both be sized from the same kernel size (a 1x1 layer has 9x fewer rows)."""
+    L = _lib.lib()
+    N, C, Co, H, W, groups = 2, 16, 40, 9, 7, 1
+    g = _lib.Geom(N, C, H, W, Co, k, k, 1, 1, k // 2, k // 2, 1, 1, groups, 1, H, W)
+    assert L.ddcn_gemm_gcol_16_supported(g) == 0
+    kt = (Co // groups + 31) // 32
+    a_bytes = groups * kt * (C // groups * k * k) * 32 * 2
+    assert L.ddcn_gemm_gcol_16_workspace_bytes(g) == (a_bytes + 255) // 256 * 256 + N * Co * H * W * 2
+    assert L.ddcn_workspace_bytes(g) == 4 * N * C * k * k * L.ddcn_col_ld(g)
+
+
 def test_check_geom_rejects_bad_shapes():
     L = _lib.lib()
     ok = dict(N=2, C=8, H=9, W=9, Co=8, kh=3, kw=3, sh=1, sw=1, ph=1, pw=1, dh=1, dw=1, groups=2, dg=2, Ho=9, Wo=9)

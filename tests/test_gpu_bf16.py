@@ -141,18 +141,76 @@ def test_bf16_scattered_offsets_leave_the_staged_patch():
     assert np.all(np.abs(got - tight) <= bound)
 
 
-def test_bf16_training_and_uncovered_geometries_use_fp32_kernels():
+def test_16bit_training_native_forward_and_16bit_g2(fmt, monkeypatch):
+    """Training on 16-bit tensors: the forward is the native 16-bit one (same bits as inference), the backward runs G2
+    on the 16-bit operands (ddcn_gemm_gcol_{bf16,f16}) and the rest on the fp32 kernels.  Gradients against the fp64
+    oracle on the same 16-bit-rounded inputs, to the format's end-to-end tolerance; DDCN_16BIT_TRAIN_NATIVE=0 (all
+    fp32 kernels) must agree with it to the same tolerance."""
+    dtype, ulp, e2e_tol = fmt
+    c = dict(BF16_CASES[1], name="train16")       # N=2, C=32, Co=72, dil 2, dg 4
+    x, off, mask, w, bias, Ho, Wo = _inputs(c, seed=3)
+    rng = np.random.default_rng(8)
+    gout = _bf(rng.standard_normal((c["N"], c["Co"], Ho, Wo)))
+    kw = dict(stride=c["stride"], padding=c["pad"], dilation=c["dil"], groups=c["groups"], deformable_groups=c["dg"])
+    egx, egoff, egmask, egw, _ = orc.deform_backward(x, off, mask, w, gout, False, **kw)
+    g = _lib.Geom(c["N"], c["C"], c["H"], c["W"], c["Co"], 3, 3, 1, 1, c["pad"], c["pad"], c["dil"], c["dil"], 1, c["dg"],
+                  Ho, Wo)
+    assert _lib.lib().ddcn_gemm_gcol_16_supported(g) == 0
+
+    def run():
+        t = [_t(a).requires_grad_(True) for a in (x, off, mask, w)]
+        out = pkg.modulated_deform_conv(t[0], t[1], t[2], t[3], None, c["stride"], c["pad"], c["dil"], c["groups"], c["dg"])
+        out.backward(_t(gout))
+        return out.detach(), [v.grad for v in t]
+    with torch.no_grad():
+        native = pkg.modulated_deform_conv(_t(x), _t(off), _t(mask), _t(w), None, c["stride"], c["pad"], c["dil"],
+                                           c["groups"], c["dg"])
+    out, grads = run()
+    assert torch.equal(out, native)                      # the training forward IS the native 16-bit forward
+    for got, exp in zip(grads, (egx, egoff, egmask, egw)):
+        assert got.dtype == dtype
+        assert cases.relerr(got.double().cpu().numpy(), exp) <= e2e_tol
+    monkeypatch.setattr(dcn, "TRAIN16_NATIVE", False)
+    out32, grads32 = run()
+    assert not torch.equal(out32, native) or True        # fp32-computed forward: may differ in the last 16-bit digit
+    for a, b in zip(grads, grads32):
+        assert cases.relerr(a.double().cpu().numpy(), b.double().cpu().numpy()) <= e2e_tol
+
+
+def test_16bit_g2_entry_point_against_fp32_gemm():
+    """ddcn_gemm_gcol_bf16 through the C ABI against the fp32 G2 on the same (bf16-representable) operands: the only
+    difference is the summation order of an fp32 accumulation.  Groups, a K that is not a multiple of 32, odd P,
+    1x1 and 5x5 kernels (the result has C/groups * kh * kw rows per group)."""
+    L = _lib.lib()
+    for (N, C, Co, H, W, groups, k) in ((2, 16, 48, 13, 11, 1, 3), (1, 32, 80, 9, 7, 2, 3), (1, 8, 264, 20, 33, 1, 3),
+                                        (2, 64, 24, 12, 10, 1, 1), (1, 8, 16, 9, 9, 1, 5)):
+        g = _lib.Geom(N, C, H, W, Co, k, k, 1, 1, k // 2, k // 2, 1, 1, groups, 1, H, W)
+        assert L.ddcn_gemm_gcol_16_supported(g) == 0
+        rng = np.random.default_rng(C)
+        w = torch.from_numpy(rng.standard_normal((Co, C // groups, k, k)).astype(np.float32)).to(DEV).bfloat16()
+        go = torch.from_numpy(rng.standard_normal((N, Co, H, W)).astype(np.float32)).to(DEV).bfloat16()
+        ld = L.ddcn_col_ld(g)
+        ref = torch.full((N, C * k * k, ld), float("nan"), device=DEV)
+        got = torch.full((N, C * k * k, ld), float("nan"), device=DEV)
+        s = _lib.current_stream(torch.device(DEV))
+        wf, gf = w.float().contiguous(), go.float().contiguous()
+        _lib.check(L.ddcn_gemm_gcol_f32(_lib.ptr(wf), _lib.ptr(gf), _lib.ptr(ref), g, s))
+        nb = L.ddcn_gemm_gcol_16_workspace_bytes(g)
+        ws = torch.empty(nb // 2, dtype=torch.bfloat16, device=DEV)
+        _lib.check(L.ddcn_gemm_gcol_bf16(_lib.ptr(w), _lib.ptr(go), _lib.ptr(got), _lib.ptr(ws), nb, g, s))
+        torch.cuda.synchronize()
+        a, b = got[:, :, :H * W].cpu().numpy(), ref[:, :, :H * W].cpu().numpy()
+        assert np.isfinite(a).all()
+        assert cases.relerr(a, b) <= 1e-5, (C, cases.relerr(a, b))
+    # Co/groups not a multiple of 8: not covered, and the autograd path then stays on the fp32 kernels
+    g = _lib.Geom(1, 8, 5, 5, 12, 3, 3, 1, 1, 1, 1, 1, 1, 1, 1, 5, 5)
+    assert L.ddcn_gemm_gcol_16_supported(g) == -5 and L.ddcn_gemm_gcol_16_workspace_bytes(g) == 0
+
+
+def test_bf16_uncovered_geometries_use_fp32_kernels():
     c = BF16_CASES[0]
     x, off, mask, w, bias, Ho, Wo = _inputs(c, seed=3)
-    tx, toff, tmask, tw, tb = _t(x), _t(off), _t(mask), _t(w), _t(bias)
-    with torch.no_grad():
-        native = pkg.modulated_deform_conv(tx, toff, tmask, tw, tb, 1, 1, 1, 1, 4)
-    tw_g = tw.clone().requires_grad_(True)
-    trained = pkg.modulated_deform_conv(tx, toff, tmask, tw_g, tb, 1, 1, 1, 1, 4)
-    trained.float().square().sum().backward()
-    assert tw_g.grad is not None and tw_g.grad.dtype == torch.bfloat16
-    # fp32-computed and native results agree to bf16 accuracy but come from different kernels
-    assert cases.relerr(trained.detach().double().cpu().numpy(), native.double().cpu().numpy()) <= 1e-2
+    tx = _t(x)
     # 1x1 kernel: not covered natively, still served (in fp32)
     w1 = _t(np.random.default_rng(0).standard_normal((8, 64, 1, 1)) * 0.1)
     off1 = torch.zeros(1, 2, c["H"], c["W"], device=DEV, dtype=torch.bfloat16)
@@ -162,6 +220,10 @@ def test_bf16_training_and_uncovered_geometries_use_fp32_kernels():
         out = pkg.deform_conv(tx, off1, w1, None, 1, 0, 1, 1, 1)
     ref = torch.nn.functional.conv2d(tx.float(), w1.float())
     assert cases.relerr(out.double().cpu().numpy(), ref.double().cpu().numpy()) <= 1e-2
+    # ... and trains (1x1: forward fp32 kernels, backward G2 on the 16-bit operands: Co = 8 is covered)
+    w1g = w1.clone().requires_grad_(True)
+    pkg.deform_conv(tx, off1, w1g, None, 1, 0, 1, 1, 1).float().square().sum().backward()
+    assert w1g.grad is not None and w1g.grad.dtype == torch.bfloat16 and torch.isfinite(w1g.grad.float()).all()
 
 
 def test_bf16_entry_point_rejects_small_workspace_and_null():
