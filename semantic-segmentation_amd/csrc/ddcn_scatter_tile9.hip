@@ -17,6 +17,8 @@
 //   escapees  : samples whose corners leave the patch are handled after the channel loop, from global memory.
 #include <stdlib.h>
 
+#include <algorithm>
+
 #include "ddcn_common.h"
 
 namespace ddcn {
@@ -29,6 +31,7 @@ constexpr int ST = 256;
 #define DDCN_S9_WPS 3
 #endif
 constexpr int SMAXCELLS = 8;
+constexpr int SMAXCELLS_WIDE = 14;       // wide-offset mode (2-channel chunks, exact fixed point): up to 57 x 57 cells
 constexpr unsigned SOOB = 0x80000000u;
 constexpr int S9_LDS_MAX = 80 * 1024;   // planner's cap on the dynamic LDS of one workgroup (two per CU)
 
@@ -41,6 +44,8 @@ struct Tile9Args {
     int TH, TW, tiles_w, tiles, groups;
     int CG, M;
     int RH, RW, RS;
+    int esc_cells;       // adaptive kernel: cost of one escaped sample in patch cells
+    int Mw_max;          // adaptive kernel: largest margin the wide (2-channel) footprint can take; 0 = never wide
     // SKB mode (few output channels, no column gradients in memory): gcol[c,k,p] = sum_o sk_w[c][k][o] * sk_g[n][o][p]
     const float *sk_w;   // weights repacked [C][9][SKB] (zero beyond sk_co)
     const float *sk_g;   // gradient w.r.t. the convolution output [N][sk_co][P]
@@ -74,8 +79,12 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t s9_rsrc(const void *base, long
 // fma(v, scale, 1.5 * 2^52) leaves round(v * scale) in the low mantissa bits (|v * scale| < 2^51), so the only rounding is
 // to 2^-50 of the chunk's largest value -- 2^-26 of an fp32 ulp of it.  Integer sums do not depend on the order of the
 // adds: the LDS part of the scatter is deterministic in this mode.
+// Patch geometry of one workgroup: margin and rows x columns of the LDS footprint.  The plain kernels take the planner's
+// (the same for every workgroup); the adaptive kernel picks one per workgroup from its own offsets.
+struct PatchGeom { int M, RH, RW, RS; };
+
 template <bool MOD, int NCELL, int SC, bool FX, int SKB = 0, bool XQ = false>
-__global__ __launch_bounds__(ST, SC == 4 ? 2 : DDCN_S9_WPS) void col2im_coord_tile9_kernel(Tile9Args a)
+__device__ __forceinline__ void tile9_body(const Tile9Args &a, const PatchGeom pg)
 {
     static_assert(!XQ || (!FX && SKB == 0), "exact fixed point: its own mode");
     constexpr bool MAXQ = FX || XQ;        // modes that need the chunk's largest |value|
@@ -89,8 +98,8 @@ __global__ __launch_bounds__(ST, SC == 4 ? 2 : DDCN_S9_WPS) void col2im_coord_ti
     __shared__ unsigned s_max[2];                                            // FX: bit pattern of gmax, per chunk parity
     double *gs = reinterpret_cast<double *>(smem_raw);                       // [SC][RS]: a wave's 64 cells -> 128 banks
     u64 *gq = reinterpret_cast<u64 *>(smem_raw);                             // FX: [SC/2][RS], channels (2j, 2j+1)
-    xvec *xs = reinterpret_cast<xvec *>(smem_raw + (size_t)a.RS * SC * GB);   // [RS][SC]
-    float *wl = reinterpret_cast<float *>(smem_raw + (size_t)a.RS * SC * (GB + 4));   // SKB: [SC][9][SKB] weights of the chunk
+    xvec *xs = reinterpret_cast<xvec *>(smem_raw + (size_t)pg.RS * SC * GB);   // [RS][SC]
+    float *wl = reinterpret_cast<float *>(smem_raw + (size_t)pg.RS * SC * (GB + 4));   // SKB: [SC][9][SKB] weights of the chunk
     const ddcn_geom &g = a.g;
     const int t = threadIdx.x;
 
@@ -104,8 +113,8 @@ __global__ __launch_bounds__(ST, SC == 4 ? 2 : DDCN_S9_WPS) void col2im_coord_ti
     const int ty = t / a.TW, tx = t - ty * a.TW;
     const int ho = tyi * a.TH + ty, wo = txi * a.TW + tx;
     const bool live = ty < a.TH && ho < g.Ho && wo < g.Wo;
-    const int rh0 = tyi * a.TH * g.sh - g.ph - a.M;
-    const int rw0 = txi * a.TW * g.sw - g.pw - a.M;
+    const int rh0 = tyi * a.TH * g.sh - g.ph - pg.M;
+    const int rw0 = txi * a.TW * g.sw - g.pw - pg.M;
     const int n = blockIdx.z;
     const int cg0 = grp * a.CG;
     const int dgi = cg0 / a.cpg;
@@ -121,9 +130,9 @@ __global__ __launch_bounds__(ST, SC == 4 ? 2 : DDCN_S9_WPS) void col2im_coord_ti
 #pragma unroll
     for (int j = 0; j < NCELL; ++j) {
         const int i = t + ST * j;
-        const int rr = i / a.RW, rc = i - rr * a.RW;
+        const int rr = i / pg.RW, rc = i - rr * pg.RW;
         const int y = rh0 + rr, xx = rw0 + rc;
-        soff[j] = (i < a.RS && y >= 0 && y < g.H && xx >= 0 && xx < g.W) ? (unsigned)((y * g.W + xx) * 4) : SOOB;
+        soff[j] = (i < pg.RS && y >= 0 && y < g.H && xx >= 0 && xx < g.W) ? (unsigned)((y * g.W + xx) * 4) : SOOB;
     }
 
     // per-tap sample state and running sums
@@ -160,7 +169,7 @@ __global__ __launch_bounds__(ST, SC == 4 ? 2 : DDCN_S9_WPS) void col2im_coord_ti
             int c = -2;
             if (live && h > -1.f && w > -1.f && h < (float)g.H && w < (float)g.W) {
                 const int rr = hl - rh0, rc = wl - rw0;
-                c = (rr >= 0 && rr + 1 < a.RH && rc >= 0 && rc + 1 < a.RW) ? rr * a.RW + rc : -1;
+                c = (rr >= 0 && rr + 1 < pg.RH && rc >= 0 && rc + 1 < pg.RW) ? rr * pg.RW + rc : -1;
             }
             cell[k] = c;
             S1[k] = S2[k] = S3[k] = S4[k] = 0.f;
@@ -173,14 +182,15 @@ __global__ __launch_bounds__(ST, SC == 4 ? 2 : DDCN_S9_WPS) void col2im_coord_ti
         for (int j = 0; j < NCELL; ++j)
 #pragma unroll
             for (int cc = 0; cc < SC; ++cc)
-                stg[j][cc] = __builtin_bit_cast(
+                if (NCELL <= 8 || ST * j < pg.RS)          // wide instantiations: skip the slots this patch does not use
+                    stg[j][cc] = __builtin_bit_cast(
                     float, __builtin_amdgcn_raw_buffer_load_b32(rx, soff[j], (unsigned)((c0 + cc) * HW * 4), 0));
     };
     auto stage_store = [&]() {
 #pragma unroll
         for (int j = 0; j < NCELL; ++j) {
             const int i = t + ST * j;
-            if (i < a.RS) {
+            if (i < pg.RS) {
                 xvec v;
 #pragma unroll
                 for (int cc = 0; cc < SC; ++cc) v[cc] = stg[j][cc];
@@ -229,13 +239,13 @@ __global__ __launch_bounds__(ST, SC == 4 ? 2 : DDCN_S9_WPS) void col2im_coord_ti
     };
 
     if (FX) {
-        for (int i = t; i < a.RS * SC / 2; i += ST) gq[i] = 0ull;
+        for (int i = t; i < pg.RS * SC / 2; i += ST) gq[i] = 0ull;
         if (t < 2) s_max[t] = 0u;
     } else if (XQ) {
-        for (int i = t; i < a.RS * SC; i += ST) gq[i] = 0ull;
+        for (int i = t; i < pg.RS * SC; i += ST) gq[i] = 0ull;
         if (t < 2) s_max[t] = 0u;
     } else {
-        for (int i = t; i < a.RS * SC; i += ST) gs[i] = 0.0;
+        for (int i = t; i < pg.RS * SC; i += ST) gs[i] = 0.0;
     }
     stage_load(cg0);
     wstage_load(cg0);
@@ -296,7 +306,7 @@ __global__ __launch_bounds__(ST, SC == 4 ? 2 : DDCN_S9_WPS) void col2im_coord_ti
                 float lh = flh[k], lw = flw[k];
                 // keep the per-tap weights and addresses out of the loop-invariant hoist (they would cost 60 VGPRs)
                 asm volatile("" : "+v"(ci), "+v"(lh), "+v"(lw));
-                const xvec a1 = xs[ci], a2 = xs[ci + 1], a3 = xs[ci + a.RW], a4 = xs[ci + a.RW + 1];
+                const xvec a1 = xs[ci], a2 = xs[ci + 1], a3 = xs[ci + pg.RW], a4 = xs[ci + pg.RW + 1];
                 const float hh = 1.f - lh, hw = 1.f - lw;
                 const float w1 = hh * hw, w2 = hh * lw, w3 = lh * hw, w4 = lh * lw;   // == K:133-140 weights
                 if (FX) {
@@ -308,7 +318,7 @@ __global__ __launch_bounds__(ST, SC == 4 ? 2 : DDCN_S9_WPS) void col2im_coord_ti
                         tgs[cc] = ldexpf(MOD ? gc * fm[k] : gc, 19 - fx_e);
                     }
                     if (!fx_bad) {
-                        u64 *q1 = gq + ci, *q3 = gq + ci + a.RW;
+                        u64 *q1 = gq + ci, *q3 = gq + ci + pg.RW;
 #pragma unroll
                         for (int pr = 0; pr < SC / 2; ++pr) {
                             const float lo = tgs[2 * pr], hi = tgs[2 * pr + 1];
@@ -316,14 +326,14 @@ __global__ __launch_bounds__(ST, SC == 4 ? 2 : DDCN_S9_WPS) void col2im_coord_ti
                                 const long long l = (long long)__float2int_rn(wl_), h = (long long)__float2int_rn(wh_);
                                 return (u64)((h << 32) + l);
                             };
-                            atomicAdd(q1 + pr * a.RS, pack(w1 * lo, w1 * hi));
-                            atomicAdd(q1 + pr * a.RS + 1, pack(w2 * lo, w2 * hi));
-                            atomicAdd(q3 + pr * a.RS, pack(w3 * lo, w3 * hi));
-                            atomicAdd(q3 + pr * a.RS + 1, pack(w4 * lo, w4 * hi));
+                            atomicAdd(q1 + pr * pg.RS, pack(w1 * lo, w1 * hi));
+                            atomicAdd(q1 + pr * pg.RS + 1, pack(w2 * lo, w2 * hi));
+                            atomicAdd(q3 + pr * pg.RS, pack(w3 * lo, w3 * hi));
+                            atomicAdd(q3 + pr * pg.RS + 1, pack(w4 * lo, w4 * hi));
                         }
                     }
                 } else if (XQ) {
-                    u64 *q1 = gq + ci, *q3 = gq + ci + a.RW;
+                    u64 *q1 = gq + ci, *q3 = gq + ci + pg.RW;
                     auto fixed = [&](float v) -> u64 {
                         const double r = __builtin_fma((double)v, xq_scale, 6755399441055744.0);   // + 1.5 * 2^52
                         return __builtin_bit_cast(u64, r) - 0x4338000000000000ull;
@@ -334,23 +344,23 @@ __global__ __launch_bounds__(ST, SC == 4 ? 2 : DDCN_S9_WPS) void col2im_coord_ti
                         S1[k] += gc * a1[cc]; S2[k] += gc * a2[cc]; S3[k] += gc * a3[cc]; S4[k] += gc * a4[cc];
                         const float tg = MOD ? gc * fm[k] : gc;
                         if (!fx_bad) {
-                            atomicAdd(q1 + cc * a.RS, fixed(w1 * tg));
-                            atomicAdd(q1 + cc * a.RS + 1, fixed(w2 * tg));
-                            atomicAdd(q3 + cc * a.RS, fixed(w3 * tg));
-                            atomicAdd(q3 + cc * a.RS + 1, fixed(w4 * tg));
+                            atomicAdd(q1 + cc * pg.RS, fixed(w1 * tg));
+                            atomicAdd(q1 + cc * pg.RS + 1, fixed(w2 * tg));
+                            atomicAdd(q3 + cc * pg.RS, fixed(w3 * tg));
+                            atomicAdd(q3 + cc * pg.RS + 1, fixed(w4 * tg));
                         }
                     }
                 } else {
-                    double *c1 = gs + ci, *c3 = gs + ci + a.RW;
+                    double *c1 = gs + ci, *c3 = gs + ci + pg.RW;
 #pragma unroll
                     for (int cc = 0; cc < SC; ++cc) {
                         const float gc = SKB ? sk_col(k, cc) : gcv[k][cc];
                         S1[k] += gc * a1[cc]; S2[k] += gc * a2[cc]; S3[k] += gc * a3[cc]; S4[k] += gc * a4[cc];
                         const float tg = MOD ? gc * fm[k] : gc;
-                        atomicAdd(c1 + cc * a.RS, (double)(w1 * tg));
-                        atomicAdd(c1 + cc * a.RS + 1, (double)(w2 * tg));
-                        atomicAdd(c3 + cc * a.RS, (double)(w3 * tg));
-                        atomicAdd(c3 + cc * a.RS + 1, (double)(w4 * tg));
+                        atomicAdd(c1 + cc * pg.RS, (double)(w1 * tg));
+                        atomicAdd(c1 + cc * pg.RS + 1, (double)(w2 * tg));
+                        atomicAdd(c3 + cc * pg.RS, (double)(w3 * tg));
+                        atomicAdd(c3 + cc * pg.RS + 1, (double)(w4 * tg));
                     }
                 }
             }
@@ -372,16 +382,16 @@ __global__ __launch_bounds__(ST, SC == 4 ? 2 : DDCN_S9_WPS) void col2im_coord_ti
 #pragma unroll
             for (int j = 0; j < NCELL; ++j) {
                 const int i = t + ST * j;
-                if (i < a.RS) {
-                    u64 wq[SC / 2];
+                if (i < pg.RS) {
+                    u64 wq[SC / 2 ? SC / 2 : 1];
                     bool any = fx_bad;
 #pragma unroll
-                    for (int pr = 0; pr < SC / 2; ++pr) { wq[pr] = gq[i + pr * a.RS]; any |= wq[pr] != 0ull; }
+                    for (int pr = 0; pr < SC / 2; ++pr) { wq[pr] = gq[i + pr * pg.RS]; any |= wq[pr] != 0ull; }
                     if (any) {
                         float *dst = gxn + (long)c0 * HW + (soff[j] >> 2);
 #pragma unroll
                         for (int pr = 0; pr < SC / 2; ++pr) {
-                            gq[i + pr * a.RS] = 0ull;
+                            gq[i + pr * pg.RS] = 0ull;
                             const int lo = (int)(unsigned)wq[pr];
                             const int hi = (int)(((long long)wq[pr] - (long long)lo) >> 32);
                             if (soff[j] != SOOB) {
@@ -403,16 +413,16 @@ __global__ __launch_bounds__(ST, SC == 4 ? 2 : DDCN_S9_WPS) void col2im_coord_ti
 #pragma unroll
             for (int j = 0; j < NCELL; ++j) {
                 const int i = t + ST * j;
-                if (i < a.RS) {
+                if (i < pg.RS) {
                     u64 wq[SC];
                     bool any = fx_bad;
 #pragma unroll
-                    for (int cc = 0; cc < SC; ++cc) { wq[cc] = gq[i + cc * a.RS]; any |= wq[cc] != 0ull; }
+                    for (int cc = 0; cc < SC; ++cc) { wq[cc] = gq[i + cc * pg.RS]; any |= wq[cc] != 0ull; }
                     if (any) {
                         float *dst = gxn + (long)c0 * HW + (soff[j] >> 2);
 #pragma unroll
                         for (int cc = 0; cc < SC; ++cc) {
-                            gq[i + cc * a.RS] = 0ull;
+                            gq[i + cc * pg.RS] = 0ull;
                             if (soff[j] != SOOB) {
                                 if (fx_bad) atomicAdd(dst + cc * HW, __uint_as_float(0x7fc00000u));
                                 else if (wq[cc] != 0ull) atomicAdd(dst + cc * HW, (float)((double)(long long)wq[cc] * inv));
@@ -425,16 +435,16 @@ __global__ __launch_bounds__(ST, SC == 4 ? 2 : DDCN_S9_WPS) void col2im_coord_ti
 #pragma unroll
             for (int j = 0; j < NCELL; ++j) {
                 const int i = t + ST * j;
-                if (i < a.RS) {
+                if (i < pg.RS) {
                     double v[SC];
                     bool any = false;
 #pragma unroll
-                    for (int cc = 0; cc < SC; ++cc) { v[cc] = gs[i + cc * a.RS]; any |= v[cc] != 0.0; }
+                    for (int cc = 0; cc < SC; ++cc) { v[cc] = gs[i + cc * pg.RS]; any |= v[cc] != 0.0; }
                     if (any) {
                         float *dst = gxn + (long)c0 * HW + (soff[j] >> 2);
 #pragma unroll
                         for (int cc = 0; cc < SC; ++cc) {
-                            gs[i + cc * a.RS] = 0.0;
+                            gs[i + cc * pg.RS] = 0.0;
                             if (soff[j] != SOOB && v[cc] != 0.0) atomicAdd(dst + cc * HW, (float)v[cc]);
                         }
                     }
@@ -518,6 +528,95 @@ __global__ __launch_bounds__(ST, SC == 4 ? 2 : DDCN_S9_WPS) void col2im_coord_ti
     }
 }
 
+template <bool MOD, int NCELL, int SC, bool FX, int SKB = 0, bool XQ = false>
+__global__ __launch_bounds__(ST, (SC == 4 || NCELL > 8) ? 2 : DDCN_S9_WPS) void col2im_coord_tile9_kernel(Tile9Args a)
+{
+    tile9_body<MOD, NCELL, SC, FX, SKB, XQ>(a, PatchGeom{a.M, a.RH, a.RW, a.RS});
+}
+
+// Adaptive footprint: every workgroup looks at its own 256 x 9 sample positions first and takes
+//   - the planner's patch (margin a.M, 4-channel chunks) when next to none of them leave it, else
+//   - a wider patch with 2-channel chunks in the same LDS allocation, margin a.M+2 ... a.Mw_max, the one that minimises
+//     (cells of the patch) + ESC_CELLS x (samples still outside): a sample outside the footprint goes through the escapee
+//     pass, which costs about as much as ESC_CELLS more cells of patch traffic per channel (profiles/r02c_*).
+// Offsets with sigma = 8 px (the reference's literal Kaiming offset init gives 6) leave the margin-6 patch for most samples
+// and took the scatter from 0.34 to 1.96 ms; with per-workgroup margins up to 16 it is 0.69 ms.
+constexpr int ESC_CELLS = 120;
+constexpr int NCELL_WIDE = 14;
+constexpr int ADAPT_STEPS = 8;         // candidate margins a.M + 2 * j
+
+// SCN / SCW: channels per chunk of the planner's and of the wide footprint: 4 / 2 in an 80 KiB allocation (two workgroups
+// per CU), 2 / 1 in 40 KiB and 168 VGPRs (three per CU: the variant that runs beside a GEMM in the two-stream backward).
+template <bool MOD, int NCELL, int SCN, int SCW>
+__global__ __launch_bounds__(ST, SCN == 4 ? 2 : DDCN_S9_WPS) void col2im_coord_tile9_adaptive_kernel(Tile9Args a)
+{
+    __shared__ int s_esc[ADAPT_STEPS];
+    const ddcn_geom &g = a.g;
+    const int t = threadIdx.x;
+    if (t < ADAPT_STEPS) s_esc[t] = 0;
+    // same workgroup -> (tile, channel group) mapping as tile9_body
+    const int nwg = a.tiles * a.groups;
+    const int bid = blockIdx.x;
+    const int q = nwg >> 3, r8 = nwg & 7, xcd = bid & 7;
+    const int logical = (xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q) + (bid >> 3);
+    const int grp = logical / a.tiles, tile = logical - grp * a.tiles;
+    const int tyi = tile / a.tiles_w, txi = tile - tyi * a.tiles_w;
+    const int ty = t / a.TW, tx = t - ty * a.TW;
+    const int ho = tyi * a.TH + ty, wo = txi * a.TW + tx;
+    const bool live = ty < a.TH && ho < g.Ho && wo < g.Wo;
+    const int n = blockIdx.z;
+    const int dgi = grp * a.CG / a.cpg;
+    const int p = live ? ho * g.Wo + wo : 0;
+    // margin-0 patch of the tile: rows rh0 .. rh0 + RH0 - 1
+    const int rh0 = tyi * a.TH * g.sh - g.ph, rw0 = txi * a.TW * g.sw - g.pw;
+    const int RH0 = a.RH - 2 * a.M, RW0 = a.RW - 2 * a.M;
+    int cnt[ADAPT_STEPS];
+#pragma unroll
+    for (int j = 0; j < ADAPT_STEPS; ++j) cnt[j] = 0;
+    {
+        const float *off = a.offset + ((long)n * g.dg + dgi) * 18 * a.P + p;
+        const int h_in = ho * g.sh - g.ph, w_in = wo * g.sw - g.pw;
+        float roh[9], row_[9];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) { roh[k] = off[(long)(2 * k) * a.P]; row_[k] = off[(long)(2 * k + 1) * a.P]; }
+#pragma unroll
+        for (int k = 0; k < 9; ++k) {
+            const int i = k / 3, j = k - 3 * i;
+            const float h = (float)(h_in + i * g.dh) + roh[k], w = (float)(w_in + j * g.dw) + row_[k];
+            if (live && h > -1.f && w > -1.f && h < (float)g.H && w < (float)g.W) {
+                const int rr = (int)floorf(h) - rh0, rc = (int)floorf(w) - rw0;
+                // the sample's corner cells are inside a margin-M patch iff M >= need
+                const int need = max(max(-rr, rr + 2 - RH0), max(-rc, rc + 2 - RW0));
+#pragma unroll
+                for (int s = 0; s < ADAPT_STEPS; ++s) cnt[s] += need > a.M + 2 * s;
+            }
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int s = 0; s < ADAPT_STEPS; ++s)
+        if (cnt[s]) atomicAdd(&s_esc[s], cnt[s]);
+    __syncthreads();
+    // cost of the planner's patch against every wide candidate (uniform over the workgroup)
+    int best = 0, best_cost = a.RS + a.esc_cells * s_esc[0];
+    if (best_cost > a.RS) {
+#pragma unroll
+        for (int s = 1; s < ADAPT_STEPS; ++s) {
+            const int M = a.M + 2 * s;
+            const int cost = (RH0 + 2 * M) * (RW0 + 2 * M) + a.esc_cells * s_esc[s] + a.RS / 8;   // + the 2-channel chunks' overhead
+            if (M <= a.Mw_max && cost < best_cost) { best_cost = cost; best = s; }
+        }
+    }
+    best = __builtin_amdgcn_readfirstlane(best);      // the same in every lane: make the branch a scalar one
+    __syncthreads();
+    if (best == 0) {
+        tile9_body<MOD, NCELL, SCN, false, 0, true>(a, PatchGeom{a.M, a.RH, a.RW, a.RS});
+    } else {
+        const int M = a.M + 2 * best, RH = RH0 + 2 * M, RW = RW0 + 2 * M;
+        tile9_body<MOD, NCELL_WIDE, SCW, false, 0, true>(a, PatchGeom{M, RH, RW, RH * RW});
+    }
+}
+
 // weight[Co][C][9] -> wp[C][9][SKB_MAX] (zero beyond Co): the 9 x SKB block of a channel is contiguous for the LDS staging
 __global__ __launch_bounds__(256) void repack_skinny_w_kernel(const float *w, float *wp, int Co, int C)
 {
@@ -556,7 +655,10 @@ int launch_col2im_coord_tile9(const float *gcol, const float *x, const float *of
     const Dims d = dims_of(g);
     if (g.kh != 3 || g.kw != 3) return DDCN_OK;
     static const int env_sc = getenv("DDCN_SCATTER_SC") ? atoi(getenv("DDCN_SCATTER_SC")) : 4;
-    const int SC = chunk_channels > 0 ? chunk_channels : env_sc;
+    // experiment: DDCN_SCATTER_WIDE=<margin> -> 2-channel chunks, one 80 KiB footprint, margin up to 16
+    const char *env_wide = getenv("DDCN_SCATTER_WIDE");
+    const int wide_m = (env_wide && !direct && chunk_channels == 0) ? atoi(env_wide) : 0;
+    const int SC = wide_m > 0 ? 2 : (chunk_channels > 0 ? chunk_channels : env_sc);
     if (SC != 2 && SC != 4) return DDCN_OK;
     if (g.H >= 32766 || g.W >= 32766 || d.cpg % SC) return DDCN_OK;
     if ((long)g.C * d.K2 * d.ld * 4 >= (1L << 31) || (long)g.C * g.H * g.W * 4 >= (1L << 31)) return DDCN_OK;
@@ -582,11 +684,13 @@ int launch_col2im_coord_tile9(const float *gcol, const float *x, const float *of
     static const int env_m = getenv("DDCN_TILE_MARGIN") ? atoi(getenv("DDCN_TILE_MARGIN")) : 6;
     static const int env_cg = getenv("DDCN_SCATTER_CG") ? atoi(getenv("DDCN_SCATTER_CG")) : 0;
     bool ok = false;
-    for (int M = env_m; M >= 0 && !ok; M -= 2) {
+    const int max_cells = (wide_m > 0 ? SMAXCELLS_WIDE : SMAXCELLS) * ST;
+    const size_t lds_cap = (SC == 4 || wide_m > 0) ? S9_LDS_MAX : S9_LDS_MAX / 2;
+    for (int M = wide_m > 0 ? wide_m : env_m; M >= 0 && !ok; M -= 2) {
         const int RH = (TH - 1) * g.sh + 2 * g.dh + 2 + 2 * M;
         const int RW = (TW - 1) * g.sw + 2 * g.dw + 2 + 2 * M;
         const size_t wbytes = direct ? (size_t)4 * 9 * SKB_MAX * sizeof(float) : 0;
-        if (RH * RW <= SMAXCELLS * ST && (size_t)RH * RW * 12 * SC + wbytes <= (size_t)(SC == 4 ? S9_LDS_MAX : S9_LDS_MAX / 2)) {
+        if (RH * RW <= max_cells && (size_t)RH * RW * 12 * SC + wbytes <= lds_cap) {
             a.M = M; a.RH = RH; a.RW = RW; a.RS = RH * RW;
             ok = true;
         }
@@ -608,7 +712,7 @@ int launch_col2im_coord_tile9(const float *gcol, const float *x, const float *of
     const char *env_fx = getenv("DDCN_SCATTER_FX");
     const bool fx = env_fx && atoi(env_fx) != 0 && SC == 4 && !direct;
     const char *env_xq = getenv("DDCN_SCATTER_XQ");
-    const bool xq = !fx && !direct && !(env_xq && atoi(env_xq) == 0);   // default; DDCN_SCATTER_XQ=0: double footprint
+    const bool xq = !fx && !direct && (wide_m > 0 || !(env_xq && atoi(env_xq) == 0));   // default; DDCN_SCATTER_XQ=0: double footprint
     const size_t smem = (size_t)a.RS * (fx ? 8 : 12) * SC + (direct ? (size_t)4 * 9 * SKB_MAX * sizeof(float) : 0);
     const int ncell = (a.RS + ST - 1) / ST;
     bool ok_lds = true;
@@ -650,7 +754,43 @@ int launch_col2im_coord_tile9(const float *gcol, const float *x, const float *of
         if (ok_lds)                                                                                              \
             hipLaunchKernelGGL((col2im_coord_tile9_kernel<false, NC, 4, false, SKB_MAX>), grid, dim3(ST), smem, stream, a); \
     } while (0)
-    if (direct) {
+    // per-workgroup adaptive footprint: the default for the plain call (4-channel chunks, exact fixed point)
+    static const int env_ad = getenv("DDCN_SCATTER_ADAPTIVE") ? atoi(getenv("DDCN_SCATTER_ADAPTIVE")) : 1;
+    int Mw_max = 0;
+    size_t smem_ad = smem;
+    const size_t ad_cap = SC == 4 ? S9_LDS_MAX : S9_LDS_MAX / 2;
+    if (env_ad && xq && wide_m == 0 && ncell <= 8) {
+        const int RH0 = a.RH - 2 * a.M, RW0 = a.RW - 2 * a.M;
+        for (int M = a.M + 2; M <= a.M + 2 * (ADAPT_STEPS - 1); M += 2) {
+            const long cells = (long)(RH0 + 2 * M) * (RW0 + 2 * M);
+            if (cells > NCELL_WIDE * ST || cells * 12 * (SC / 2) > (long)ad_cap) break;
+            Mw_max = M;
+            smem_ad = std::max(smem, (size_t)cells * 12 * (SC / 2));
+        }
+    }
+    a.Mw_max = Mw_max;
+    static const int env_esc = getenv("DDCN_SCATTER_ESC_CELLS") ? atoi(getenv("DDCN_SCATTER_ESC_CELLS")) : ESC_CELLS;
+    a.esc_cells = env_esc;
+#define DDCN_S9_LAUNCH_AD(MOD, NC, SCN, SCW)                                                                     \
+    do {                                                                                                         \
+        static std::atomic<uint64_t> raised{0};                                                                  \
+        ok_lds = raise_lds_limit((const void *)&col2im_coord_tile9_adaptive_kernel<MOD, NC, SCN, SCW>, S9_LDS_MAX, raised); \
+        if (ok_lds)                                                                                              \
+            hipLaunchKernelGGL((col2im_coord_tile9_adaptive_kernel<MOD, NC, SCN, SCW>), grid, dim3(ST), smem_ad, stream, a); \
+    } while (0)
+#define DDCN_S9_LAUNCH_ADN(NC)                                                                                   \
+    do {                                                                                                         \
+        if (mask && SC == 4) DDCN_S9_LAUNCH_AD(true, NC, 4, 2);                                                  \
+        else if (SC == 4) DDCN_S9_LAUNCH_AD(false, NC, 4, 2);                                                    \
+        else if (mask) DDCN_S9_LAUNCH_AD(true, NC, 2, 1);                                                        \
+        else DDCN_S9_LAUNCH_AD(false, NC, 2, 1);                                                                 \
+    } while (0)
+    if (Mw_max > 0) {
+        if (ncell <= 2) DDCN_S9_LAUNCH_ADN(2);
+        else if (ncell <= 4) DDCN_S9_LAUNCH_ADN(4);
+        else if (ncell <= 6) DDCN_S9_LAUNCH_ADN(6);
+        else DDCN_S9_LAUNCH_ADN(8);
+    } else if (direct) {
         if (ncell <= 2) DDCN_S9_LAUNCH_DIRECT(2);
         else if (ncell <= 4) DDCN_S9_LAUNCH_DIRECT(4);
         else if (ncell <= 6) DDCN_S9_LAUNCH_DIRECT(6);
@@ -658,7 +798,10 @@ int launch_col2im_coord_tile9(const float *gcol, const float *x, const float *of
     } else if (ncell <= 2) DDCN_S9_LAUNCH(2);
     else if (ncell <= 4) DDCN_S9_LAUNCH(4);
     else if (ncell <= 6) DDCN_S9_LAUNCH(6);
-    else DDCN_S9_LAUNCH(8);
+    else if (ncell <= 8) DDCN_S9_LAUNCH(8);
+    else { if (mask) DDCN_S9_LAUNCH_XQ2(true, 14, 2); else DDCN_S9_LAUNCH_XQ2(false, 14, 2); }
+#undef DDCN_S9_LAUNCH_AD
+#undef DDCN_S9_LAUNCH_ADN
 #undef DDCN_S9_LAUNCH_DIRECT
 #undef DDCN_S9_LAUNCH2
 #undef DDCN_S9_LAUNCH

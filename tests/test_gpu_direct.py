@@ -103,13 +103,16 @@ def test_direct_backward_full_size_mask_branch_against_oracle():
     assert cases.relerr(gw.cpu().numpy(), egw) <= BWD_TOL
 
 
+@pytest.mark.parametrize("spread", [1, 4], ids=["offsets_x1", "offsets_x4"])
 @pytest.mark.parametrize("modulated", [True, False], ids=["modulated", "plain"])
-def test_two_stream_saved_backward_matches_single_stream_and_oracle(modulated):
+def test_two_stream_saved_backward_matches_single_stream_and_oracle(modulated, spread):
     """ddcn_deform_conv_backward_saved_2s_f32 (G3 on a side stream beside the scatter) against the oracle and against
-    the one-stream entry point on the same saved columns."""
+    the one-stream entry point on the same saved columns.  offsets_x4: most samples leave the planner's footprint, so the
+    workgroups of both adaptive scatter kernels (4/2-channel chunks one-stream, 2/1 beside the GEMM) take wide patches."""
     L = _lib.lib()
     c = cases.C("two_stream", N=2, Ci=64, Co=48, H=33, W=29, pad=2, dil=2, bias=True, modulated=modulated, seed=60)
     inp = {k: (None if v is None else v.astype(np.float32).astype(np.float64)) for k, v in cases.make_inputs(c).items()}
+    inp["offset"] = inp["offset"] * spread       # a power of two: the quantised offsets stay off the integer grid
     Ho, Wo, _ = cases.geometry(c)
     g = _lib.Geom(c["N"], c["Ci"], c["H"], c["W"], c["Co"], 3, 3, 1, 1, 2, 2, 2, 2, 1, 1, Ho, Wo)
     x, w, off, gout, b = (_dev(inp[k]) for k in ("x", "weight", "offset", "gout", "bias"))
