@@ -263,6 +263,22 @@ int ddcn_gemm_gcol_bf16(const void *weight, const void *grad_out, float *gcol, v
 int ddcn_gemm_gcol_f16(const void *weight, const void *grad_out, float *gcol, void *workspace, size_t workspace_bytes,
                        const ddcn_geom *g, void *stream);
 
+/* G3 of the backward on 16-bit tensors (the reference's half instantiation of H:311-320 / H:539-544): grad_weight
+ * (fp32, [Co][C/groups][3][3], accumulated: gw += ...) from the bfloat16 / float16 input, offset, mask (NULL = the
+ * non-modulated op) and grad_out.  The columns are recomputed by the 16-bit im2col straight into the layout the matrix
+ * core contracts over pixels (pixel octets, never fp32), the product runs on v_mfma_f32_16x16x32_{bf16,f16} with fp32
+ * accumulation, split over images and pixel ranges.  `workspace`: ddcn_gweight_16_workspace_bytes().  Covered
+ * (ddcn_gweight_16_supported() == 0): what ddcn_bf16_supported() covers, with Co/groups a multiple of 8 and a patch that
+ * fits the LDS tile kernel. */
+size_t ddcn_gweight_16_workspace_bytes(const ddcn_geom *g);
+int ddcn_gweight_16_supported(const ddcn_geom *g);
+int ddcn_deform_conv_gweight_bf16(const void *x, const void *offset, const void *mask, const void *grad_out,
+                                  float *grad_weight, void *workspace, size_t workspace_bytes, const ddcn_geom *g,
+                                  void *stream);
+int ddcn_deform_conv_gweight_f16(const void *x, const void *offset, const void *mask, const void *grad_out,
+                                 float *grad_weight, void *workspace, size_t workspace_bytes, const ddcn_geom *g,
+                                 void *stream);
+
 /* ---------------------------------------------------------------- deformable PS-RoI pooling
  * Replaces the reference's second extension, `detseg.ops.dcn.deform_pool_cuda`:
  *   PP = detseg/ops/dcn/deform_pool.py

@@ -599,6 +599,44 @@ int ddcn_gemm_gcol_f16(const void *weight, const void *grad_out, float *gcol, vo
     return gemm_gcol_16(false, weight, grad_out, gcol, workspace, workspace_bytes, g, stream);
 }
 
+// ---------------------------------------------------------------- 16-bit backward: grad_weight from 16-bit tensors
+size_t ddcn_gweight_16_workspace_bytes(const ddcn_geom *g)
+{
+    if (check_geom(g) != DDCN_OK || gweight16_supported(*g) != DDCN_OK) return 0;
+    return gweight16_workspace_bytes(*g);
+}
+
+int ddcn_gweight_16_supported(const ddcn_geom *g)
+{
+    TRY(check_geom(g));
+    return gweight16_supported(*g);
+}
+
+static int gweight_16(bool bf16, const void *x, const void *offset, const void *mask, const void *grad_out,
+                      float *grad_weight, void *ws, size_t ws_bytes, const ddcn_geom *g, void *stream)
+{
+    REQUIRE(x); REQUIRE(offset); REQUIRE(grad_out); REQUIRE(grad_weight);
+    TRY(check_geom(g));
+    TRY(gweight16_supported(*g));
+    if (!ws || ws_bytes < gweight16_workspace_bytes(*g) || ((uintptr_t)ws & 15))
+        return fail(DDCN_ERR_WORKSPACE, "16-bit G3 workspace of %zu bytes (16-byte aligned), need %zu", ws_bytes,
+                    gweight16_workspace_bytes(*g));
+    return bf16 ? launch_gweight_bf16(x, offset, mask, grad_out, grad_weight, ws, *g, (hipStream_t)stream)
+                : launch_gweight_f16(x, offset, mask, grad_out, grad_weight, ws, *g, (hipStream_t)stream);
+}
+
+int ddcn_deform_conv_gweight_bf16(const void *x, const void *offset, const void *mask, const void *grad_out,
+                                  float *grad_weight, void *workspace, size_t workspace_bytes, const ddcn_geom *g, void *stream)
+{
+    return gweight_16(true, x, offset, mask, grad_out, grad_weight, workspace, workspace_bytes, g, stream);
+}
+
+int ddcn_deform_conv_gweight_f16(const void *x, const void *offset, const void *mask, const void *grad_out,
+                                 float *grad_weight, void *workspace, size_t workspace_bytes, const ddcn_geom *g, void *stream)
+{
+    return gweight_16(false, x, offset, mask, grad_out, grad_weight, workspace, workspace_bytes, g, stream);
+}
+
 int ddcn_deform_psroi_pool_forward_f32(const float *data, const float *rois, const float *offset, float *out,
                                        float *out_count, const ddcn_roi_geom *g, void *stream)
 {

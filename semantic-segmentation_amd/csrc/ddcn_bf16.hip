@@ -32,6 +32,8 @@
 
 #include <stdlib.h>
 
+#include <algorithm>
+
 namespace ddcn {
 namespace {
 
@@ -101,6 +103,15 @@ struct Bf16Args {
     int pair, rw_shift;   // pair staging: patch starts rw_shift columns further left so that it starts on an even column
     float *outf;          // GEMM result as fp32 rows of ldc floats (the column gradients of the 16-bit backward) instead of `out`
     long ldc;
+    int out_atomic;       // outf is accumulated with atomics (split-K / per-image partial products of G3)
+    // generic operand placement of the LDS-DMA GEMMs (set by gemm_operands(); the forward's values reproduce round 1)
+    long sA_grp;          // elements between the A slabs of two groups / of two images
+    long sA_img;
+    long sB_img, sB_grp;  // 16-byte chunks between the B slabs of two images / groups
+    int ldb;              // 16-byte chunks per k-octet row of B (>= the columns P this GEMM reads)
+    int kt_per;           // K tiles (32 k) per split; blockIdx.z = split
+    // im2col with pixel octets (G3 of the 16-bit backward): col[n][tiles*32][Ktot][8], pixel order = (tile, lane)
+    int pixoct;
 };
 
 constexpr int IT = 256;  // im2col threads
@@ -346,11 +357,57 @@ __global__ __launch_bounds__(IT, 2) void im2col_bf16_tile_kernel(const Bf16Args 
     __syncthreads();
     const int nocts = a.CG / 8;
     u32x4 *colp = (u32x4 *)a.col + ((long)n * a.KO + (long)(c_begin / 8) * 9) * a.P + p;
+    // Pixel-octet mode (the B operand of G3, which contracts over pixels): col[n][pixel octet][row][8 pixels] with the
+    // pixels in (tile, lane) order -- lanes outside the map are zero columns -- and rows ordered (group, tap, channel), so
+    // that the 8 channels of an octet are 8 consecutive rows.  Each wave transposes its 64 x 8 block through 1 KiB of LDS
+    // behind the patch buffers: lane (q, i) collects channel i of the 8 pixels of lane group q and stores one 16-byte
+    // vector; the 8 lanes of a group write 128 contiguous bytes.
+    const int Cg = a.C / a.groups;
+    u32x4 *tb = patch + 2 * a.RS + (t & ~63);                  // this wave's 64 slots
+    const long pix8 = (long)a.tiles * (IT / 8);                // pixel octets per image
+    auto pixoct_row = [&](int oc, int k) -> long {             // row of channel c_begin + 8*oc (+ i) for tap k
+        const int c = c_begin + oc * 8, grp = c / Cg;
+        return (long)grp * a.Kg + (long)k * Cg + (c - grp * Cg);
+    };
+    auto pixoct_store = [&](int oc, int k, u32x4 o) {
+        tb[t & 63] = o;
+        __builtin_amdgcn_wave_barrier();
+        const unsigned short *hw = (const unsigned short *)(tb + (t & 56)) + (t & 7);   // lane group's 8 pixels, channel t & 7
+        unsigned short v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = hw[e * 8];
+        __builtin_amdgcn_wave_barrier();
+        u32x4 r;
+        r.x = v[0] | ((unsigned)v[1] << 16); r.y = v[2] | ((unsigned)v[3] << 16);
+        r.z = v[4] | ((unsigned)v[5] << 16); r.w = v[6] | ((unsigned)v[7] << 16);
+        ((u32x4 *)a.col)[(((long)n * pix8 + (long)tile * (IT / 8) + (t >> 3)) * a.KO * 8) + pixoct_row(oc, k) + (t & 7)] = r;
+    };
+    // one element of a pixel-octet column: lane tl of this tile, channel c_begin + 8*oc + e, tap k
+    auto pixoct_put = [&](int oc, int k, int tl, u32x4 o) {
+        bf16_t *dst = (bf16_t *)a.col + ((((long)n * pix8 + (long)tile * (IT / 8) + (tl >> 3)) * a.KO * 8) + pixoct_row(oc, k)) * 8 + (tl & 7);
+        dst[0] = (bf16_t)o.x; dst[8] = (bf16_t)(o.x >> 16); dst[16] = (bf16_t)o.y; dst[24] = (bf16_t)(o.y >> 16);
+        dst[32] = (bf16_t)o.z; dst[40] = (bf16_t)(o.z >> 16); dst[48] = (bf16_t)o.w; dst[56] = (bf16_t)(o.w >> 16);
+    };
     for (int oc = 0; oc < nocts; ++oc) {
         const u32x4 *cur = (oc & 1) ? buf1 : buf0;
         u32x4 *nxt = (oc & 1) ? buf0 : buf1;
         if (oc + 1 < nocts) stage_load((oc + 1) * 8);
-        if (live) {
+        if (a.pixoct) {
+#pragma unroll
+            for (int k = 0; k < 9; ++k) {
+                const bool use = live && cell[k] >= 0;         // escapees are filled in by the second pass, the rest is zero
+                const int ci = use ? cell[k] : 0;
+                const u32x4 a1 = cur[ci], a2 = cur[ci + 1], a3 = cur[ci + a.RW], a4 = cur[ci + a.RW + 1];
+                const float q1 = use ? w1[k] : 0.f, q2 = use ? w2[k] : 0.f, q3 = use ? w3[k] : 0.f, q4 = use ? w4[k] : 0.f;
+                u32x4 o;
+                o.x = blend_pair<T>(a1.x, a2.x, a3.x, a4.x, q1, q2, q3, q4);
+                o.y = blend_pair<T>(a1.y, a2.y, a3.y, a4.y, q1, q2, q3, q4);
+                o.z = blend_pair<T>(a1.z, a2.z, a3.z, a4.z, q1, q2, q3, q4);
+                o.w = blend_pair<T>(a1.w, a2.w, a3.w, a4.w, q1, q2, q3, q4);
+                if (!use) o = u32x4{0u, 0u, 0u, 0u};           // 0 * Inf of a staged cell must not leak into a zero column
+                pixoct_store(oc, k, o);
+            }
+        } else if (live) {
 #pragma unroll
             for (int k = 0; k < 9; ++k) {
                 if (cell[k] == -1) continue;   // escapee: second pass
@@ -390,14 +447,16 @@ __global__ __launch_bounds__(IT, 2) void im2col_bf16_tile_kernel(const Bf16Args 
             const unsigned slot = atomicAdd(cnt, 1u);
             if (slot < cap) {
                 u32x4 e;
-                e.x = (unsigned)p | ((unsigned)k << 27);
+                e.x = (unsigned)(a.pixoct ? t : p) | ((unsigned)k << 27);
                 e.y = __float_as_uint(h); e.z = __float_as_uint(w); e.w = __float_as_uint(m);
                 patch[1 + slot] = e;
             } else {
 #pragma unroll 2
-                for (int oc = 0; oc < nocts; ++oc)
-                    colp[((long)oc * 9 + k) * a.P] =
-                        sample_octet_global<T>(xb + (long)oc * 8 * HW, HW, a.H, a.W, h, w, m);
+                for (int oc = 0; oc < nocts; ++oc) {
+                    const u32x4 o = sample_octet_global<T>(xb + (long)oc * 8 * HW, HW, a.H, a.W, h, w, m);
+                    if (a.pixoct) pixoct_put(oc, k, t, o);
+                    else colp[((long)oc * 9 + k) * a.P] = o;
+                }
             }
         }
     }
@@ -408,9 +467,10 @@ __global__ __launch_bounds__(IT, 2) void im2col_bf16_tile_kernel(const Bf16Args 
         const int oc = it / listed, ei = it - oc * listed;
         const u32x4 e = patch[1 + ei];
         const int ep = (int)(e.x & 0x7ffffffu), k = (int)(e.x >> 27);
-        colg[((long)oc * 9 + k) * a.P + ep] = sample_octet_global<T>(xb + (long)oc * 8 * HW, HW, a.H, a.W,
-                                                                    __uint_as_float(e.y), __uint_as_float(e.z),
-                                                                    __uint_as_float(e.w));
+        const u32x4 o = sample_octet_global<T>(xb + (long)oc * 8 * HW, HW, a.H, a.W, __uint_as_float(e.y),
+                                               __uint_as_float(e.z), __uint_as_float(e.w));
+        if (a.pixoct) pixoct_put(oc, k, ep, o);
+        else colg[((long)oc * 9 + k) * a.P + ep] = o;
     }
 }
 
@@ -579,14 +639,18 @@ void gemm16_dma_kernel(const Bf16Args a)
     const int L = xcd_logical(blockIdx.x, tiles_m * tiles_n);
     const int m0 = (L % tiles_m) * BMK, n0 = (L / tiles_m) * BNW;
     const int img = blockIdx.y / a.groups, grp = blockIdx.y % a.groups;
-    const int M = a.Cog, K = a.Kg, KOg = K / 8;
+    const int M = a.Cog, K = a.Kg;
 
-    // weights as repack_w_blocked_kernel leaves them: [group][K/32][M][32], zero-padded in k
-    const int ntiles = (K + DK - 1) / DK;
-    const __amdgpu_buffer_rsrc_t rA = uniform_rsrc(a.weight + (long)grp * ntiles * M * DK,
+    // A as repack_w_blocked_kernel leaves it: [slab][K/32][M][32], zero-padded in k; B: k-octet rows of a.ldb chunks.
+    // Split-K (blockIdx.z): this workgroup contracts K tiles kt0 .. kt0 + ntiles - 1; the descriptors start there.
+    const int kt_all = (K + DK - 1) / DK;
+    const int kt0 = blockIdx.z * a.kt_per;
+    const int ntiles = min(a.kt_per, kt_all - kt0);
+    const int KOg = K / 8 - kt0 * 4;          // k-octets of B from kt0 on (the rest of a partial last tile reads as zeros)
+    const __amdgpu_buffer_rsrc_t rA = uniform_rsrc(a.weight + a.sA_img * img + a.sA_grp * grp + (long)kt0 * M * DK,
                                                    (unsigned)((long)ntiles * M * DK * 2));
-    const __amdgpu_buffer_rsrc_t rB = uniform_rsrc((const u32x4 *)a.col + ((long)img * a.KO + (long)grp * KOg) * a.P,
-                                                   (unsigned)((long)KOg * a.P * 16));
+    const __amdgpu_buffer_rsrc_t rB = uniform_rsrc((const u32x4 *)a.col + a.sB_img * img + a.sB_grp * grp + (long)kt0 * 4 * a.ldb,
+                                                   (unsigned)((((long)KOg - 1) * a.ldb + a.P) * 16));
 
     // this thread's RA chunks of A and RB of B per stage; request r of wave w fills ring chunks (r*NWAVES+w)*64 + lane
     unsigned offA[RA], offB[RB];
@@ -600,7 +664,7 @@ void gemm16_dma_kernel(const Bf16Args a)
     for (int r = 0; r < RB; ++r) {
         const int q = (r * NWAVES + wave) * 64 + lane;
         const int oct = q / BNW, nn = n0 + (q % BNW);
-        offB[r] = (nn < a.P) ? (unsigned)((oct * a.P + nn) * 16) : DMA_OOB;
+        offB[r] = (nn < a.P) ? (unsigned)((oct * a.ldb + nn) * 16) : DMA_OOB;
     }
     auto request = [&](int kt) {
         const int st = kt % NS, k0 = kt * DK;
@@ -612,7 +676,7 @@ void gemm16_dma_kernel(const Bf16Args a)
         }
 #pragma unroll
         for (int r = 0; r < RB; ++r) {
-            const unsigned vb = offB[r] != DMA_OOB ? offB[r] + (unsigned)((k0 / 8) * a.P * 16) : DMA_OOB;
+            const unsigned vb = offB[r] != DMA_OOB ? offB[r] + (unsigned)((k0 / 8) * a.ldb * 16) : DMA_OOB;
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rB, (lds_void *)(base + BMK * 64 + r * (NWAVES * 1024)), 16, vb, 0,
                                                      0, 0);
         }
@@ -714,7 +778,8 @@ void gemm16_dma_kernel(const Bf16Args a)
                 const int col = n0 + wn * 64 + j * 16 + r16;
                 const float v = acc[i][j][e] + bv;
                 if (col < a.P) {
-                    if (a.outf) a.outf[((long)img * a.Co + (long)grp * M + row) * a.ldc + col] = v;
+                    if (a.out_atomic) atomicAdd(a.outf + ((long)grp * M + row) * a.ldc + col, v);   // summed over images and splits
+                    else if (a.outf) a.outf[((long)img * a.Co + (long)grp * M + row) * a.ldc + col] = v;
                     else C[(long)row * a.P + col] = (bf16_t)T::pack2(v, 0.f);
                 }
             }
@@ -767,7 +832,8 @@ static bool plan_bf16_tile(Bf16Args &a, const ddcn_geom &g)
         a.RW = (TW - 1) * g.sw + 2 * g.dw + 2 * M + 2 + a.rw_shift;
         if (a.pair) a.RW += a.RW & 1;
         a.RS = a.RH * a.RW;
-        if (a.RS <= 8 * IT) break;   // 2 buffers x 2048 cells x 16 B = 64 KB of LDS
+        // 2 buffers x 2048 cells x 16 B = 64 KB of LDS; the pixel-octet mode keeps 4 KB of them for its transposition slots
+        if (a.RS <= (a.pixoct ? 8 * IT - IT / 2 : 8 * IT)) break;
         if (M <= 2) return false;
     }
     a.M = M;
@@ -783,7 +849,7 @@ static bool plan_bf16_tile(Bf16Args &a, const ddcn_geom &g)
 template <typename T, bool MOD>
 static void run_bf16_tile(const Bf16Args &a, const dim3 &grid, hipStream_t stream)
 {
-    const size_t lds = (size_t)2 * a.RS * 16;
+    const size_t lds = (size_t)2 * a.RS * 16 + (a.pixoct ? IT * 16 : 0);   // + the waves' transposition slots
     const int ncell = (a.RS + IT - 1) / IT;
     if (a.pair) {
         if (ncell <= 4) hipLaunchKernelGGL((im2col_bf16_tile_kernel<T, MOD, 4, true>), grid, dim3(IT), lds, stream, a);
@@ -794,6 +860,17 @@ static void run_bf16_tile(const Bf16Args &a, const dim3 &grid, hipStream_t strea
         else if (ncell <= 6) hipLaunchKernelGGL((im2col_bf16_tile_kernel<T, MOD, 6, false>), grid, dim3(IT), lds, stream, a);
         else hipLaunchKernelGGL((im2col_bf16_tile_kernel<T, MOD, 8, false>), grid, dim3(IT), lds, stream, a);
     }
+}
+
+// Operand placement of the round-1 forward GEMM: W'' slabs per group, columns [n][K/8][P][8] with the groups splitting k
+static void gemm_operands_forward(Bf16Args &a)
+{
+    const long kt = (a.Kg + 31) / 32;
+    a.sA_grp = kt * a.Cog * 32; a.sA_img = 0;
+    a.sB_img = (long)a.KO * a.P; a.sB_grp = (long)(a.Kg / 8) * a.P;
+    a.ldb = a.P;
+    a.kt_per = (int)kt;
+    a.out_atomic = 0;
 }
 
 template <typename T>
@@ -813,6 +890,7 @@ static int forward_16(const void *x, const void *weight, const void *bias, const
     a.Cog = g.Co / g.groups;
     a.tiles_m = (a.Cog + BM - 1) / BM;
     a.tiles_n = (a.P + BN - 1) / BN;
+    gemm_operands_forward(a);
 
     // GEMM variant: LDS-DMA ring (default 4 stages; DDCN_BF16_GEMM_STAGES=0 selects the register-staged kernel).  The
     // DMA kernels address W and one (image, group) columns slab with 31-bit byte offsets.
@@ -966,6 +1044,7 @@ static int gemm_gcol_16(const void *weight, const void *gout, float *gcol, void 
     a.Cog = M;                    // rows per group
     a.Kg = Cog;                   // reduction length per group
     a.KO = g.Co / 8;              // k-octets of one image of B
+    gemm_operands_forward(a);
     // tile class as in the forward: 256x256 tiles when they fill the chip, else 128x128 (4 stages)
     const long tiles_sq = (long)((M + 255) / 256) * ((P + 255) / 256) * g.N * g.groups;
     if (M >= 192 && tiles_sq >= 256) {
@@ -989,6 +1068,167 @@ int launch_gemm_gcol_bf16(const void *weight, const void *gout, float *gcol, voi
 int launch_gemm_gcol_f16(const void *weight, const void *gout, float *gcol, void *ws, const ddcn_geom &g, hipStream_t stream)
 {
     return gemm_gcol_16<F16>(weight, gout, gcol, ws, g, stream);
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------
+// G3 of the 16-bit backward: grad_weight[g] (Cog x Kg) += sum_n grad_out[n][g] (Cog x P) * col[n][g]^T, contracted over
+// the pixels (H:539-544 under the half instantiation).  The pixels are taken in the im2col kernel's own order -- (tile,
+// lane), lanes outside the map being zero columns -- so k = tiles * 256 per image, always whole 32-k tiles:
+//   A = grad_out gathered into [n][group][k/32][Cog][32] (zero outside the map)        gout_pixblock_kernel
+//   B = columns as pixel octets [n][k/8][C*9 rows][8], rows (group, tap, channel)        im2col_bf16_tile_kernel, pixoct
+//   C = fp32 partial sums added into gw'[Co][tap][Cg] (atomics: images x K splits), then gw[o][c][tap] += gw'[o][tap][c].
+namespace {
+
+__global__ __launch_bounds__(256) void gout_pixblock_kernel(const bf16_t *gout, bf16_t *ap, long total, int Co, int Cog,
+                                                           int KT, int tiles_w, int Ho, int Wo)
+{
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int k32 = (int)(i & 31);
+    long rest = i >> 5;
+    const int o = (int)(rest % Cog); rest /= Cog;
+    const int kt = (int)(rest % KT); rest /= KT;
+    const int groups = Co / Cog;
+    const int grp = (int)(rest % groups);
+    const long n = rest / groups;
+    const int idx = kt * 32 + k32, tile = idx >> 8, t = idx & 255;
+    const int ho = (tile / tiles_w) * TH + (t >> 5), wo = (tile % tiles_w) * TW + (t & 31);
+    ap[i] = (ho < Ho && wo < Wo) ? gout[((n * Co + (long)grp * Cog + o) * Ho + ho) * Wo + wo] : (bf16_t)0;
+}
+
+__global__ __launch_bounds__(256) void zero_f32_kernel(float *p, long n)
+{
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) p[i] = 0.f;
+}
+
+// gw[o][c][tap] += gwp[o][tap][c]   (o over all Co rows, c inside the row's group)
+__global__ __launch_bounds__(256) void gweight_finish_kernel(const float *gwp, float *gw, long total, int Cg)
+{
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int tap = (int)(i % 9);
+    const long oc = i / 9;
+    const int c = (int)(oc % Cg);
+    const long o = oc / Cg;
+    gw[i] += gwp[(o * 9 + tap) * Cg + c];
+}
+
+struct Gw16Plan { size_t b_bytes, a_bytes, p_bytes; long kpix; };
+
+Gw16Plan gw16_plan(const ddcn_geom &g)
+{
+    Gw16Plan pl;
+    const long tiles = (long)((g.Wo + TW - 1) / TW) * ((g.Ho + TH - 1) / TH);
+    pl.kpix = tiles * IT;
+    pl.b_bytes = round_up((size_t)g.N * pl.kpix * g.C * 9 * 2, 256);
+    pl.a_bytes = round_up((size_t)g.N * pl.kpix * g.Co * 2, 256);
+    pl.p_bytes = round_up((size_t)g.Co * (g.C / g.groups) * 9 * 4, 256);
+    return pl;
+}
+
+}  // namespace
+
+int gweight16_supported(const ddcn_geom &g)
+{
+    if (int rc = bf16_supported(g)) return rc;
+    const Gw16Plan pl = gw16_plan(g);
+    const long Cog = g.Co / g.groups, Kg = (long)(g.C / g.groups) * 9;
+    if (Cog % 8) return fail(DDCN_ERR_UNSUPPORTED, "16-bit G3: Co/groups must be a multiple of 8 (Co=%d groups=%d)", g.Co, g.groups);
+    // 31-bit byte offsets inside one image's B slab and one (image, group) A slab
+    if (pl.kpix / 8 * (long)g.C * 9 * 16 >= (1L << 31) || pl.kpix * Cog * 2 >= (1L << 31) || Kg >= (1L << 27))
+        return fail(DDCN_ERR_UNSUPPORTED, "16-bit G3: tensor too large");
+    Bf16Args a = {};
+    a.pixoct = 1;
+    if (!plan_bf16_tile(a, g)) return fail(DDCN_ERR_UNSUPPORTED, "16-bit G3: the im2col patch of this geometry does not fit the LDS tile kernel");
+    return DDCN_OK;
+}
+
+size_t gweight16_workspace_bytes(const ddcn_geom &g)
+{
+    const Gw16Plan pl = gw16_plan(g);
+    return pl.b_bytes + pl.a_bytes + pl.p_bytes;
+}
+
+template <typename T>
+static int gweight_16(const void *x, const void *offset, const void *mask, const void *gout, float *gw, void *ws,
+                      const ddcn_geom &g, hipStream_t stream)
+{
+    if (int rc = gweight16_supported(g)) return rc;
+    const Gw16Plan pl = gw16_plan(g);
+    const int Cog = g.Co / g.groups, Cg = g.C / g.groups, Kg = Cg * 9, P = g.Ho * g.Wo;
+    bf16_t *colp = (bf16_t *)ws;
+    bf16_t *ap = (bf16_t *)((char *)ws + pl.b_bytes);
+    float *gwp = (float *)((char *)ws + pl.b_bytes + pl.a_bytes);
+
+    // B: columns as pixel octets
+    Bf16Args a = {};
+    a.x = (const bf16_t *)x; a.offset = (const bf16_t *)offset; a.mask = (const bf16_t *)mask;
+    a.col = colp;
+    a.N = g.N; a.C = g.C; a.H = g.H; a.W = g.W; a.Co = g.Co; a.Ho = g.Ho; a.Wo = g.Wo; a.P = P;
+    a.sh = g.sh; a.sw = g.sw; a.ph = g.ph; a.pw = g.pw; a.dh = g.dh; a.dw = g.dw;
+    a.groups = g.groups; a.dg = g.dg; a.cpg = g.C / g.dg;
+    a.KO = g.C * 9 / 8;
+    a.Kg = Kg;
+    a.pixoct = 1;
+    if (!plan_bf16_tile(a, g)) return fail(DDCN_ERR_UNSUPPORTED, "16-bit G3: no LDS tile plan");
+    {
+        const dim3 grid((unsigned)(a.tiles * (g.C / a.CG)), 1, (unsigned)g.N);
+        if (mask) run_bf16_tile<T, true>(a, grid, stream);
+        else run_bf16_tile<T, false>(a, grid, stream);
+        if (int rc = check_launch("im2col_16_pixoct")) return rc;
+    }
+    // A: grad_out in the same pixel order, blocked; the partial result starts at zero
+    const int KT = (int)(pl.kpix / 32);
+    const long atotal = (long)g.N * g.Co * pl.kpix;
+    hipLaunchKernelGGL(gout_pixblock_kernel, dim3((unsigned)((atotal + 255) / 256)), dim3(256), 0, stream,
+                       (const bf16_t *)gout, ap, atotal, g.Co, Cog, KT, a.tiles_w, g.Ho, g.Wo);
+    const long wtotal = (long)g.Co * Kg;
+    hipLaunchKernelGGL(zero_f32_kernel, dim3((unsigned)((wtotal + 255) / 256)), dim3(256), 0, stream, gwp, wtotal);
+    if (int rc = check_launch("gout_pixblock")) return rc;
+
+    Bf16Args b = {};
+    b.weight = ap; b.col = colp; b.outf = gwp; b.ldc = Kg; b.out_atomic = 1;
+    b.N = g.N; b.groups = g.groups;
+    b.P = Kg;                      // columns of the product: the rows of one group's columns
+    b.Cog = Cog; b.Co = g.Co;      // rows: the group's output channels
+    b.Kg = (int)pl.kpix;           // contraction: the pixels of one image
+    b.sA_img = (long)g.Co * pl.kpix; b.sA_grp = (long)Cog * pl.kpix;
+    b.ldb = g.C * 9;
+    b.sB_img = (pl.kpix / 8) * (long)b.ldb; b.sB_grp = Kg;
+    // K splits: enough workgroups for the chip
+    const bool sq = Cog >= 192;    // 256 x 256 tiles
+    const long tiles = sq ? (long)((Cog + 255) / 256) * ((Kg + 255) / 256) : (long)((Cog + 127) / 128) * ((Kg + 127) / 128);
+    long splits = std::max<long>(1, (sq ? 256 : 512) / std::max<long>(1, tiles * g.N * g.groups));
+    splits = std::min<long>(splits, std::max(1, KT / 16));
+    b.kt_per = (int)((KT + splits - 1) / splits);
+    const unsigned nz = (unsigned)((KT + b.kt_per - 1) / b.kt_per);
+    if (sq) {
+        const dim3 g8((unsigned)tiles, (unsigned)(g.N * g.groups), nz);
+        static std::atomic<uint64_t> raised{0};
+        if (!raise_lds_limit((const void *)gemm16_dma_kernel<T, 4, 4, 4>, 4 * 32768, raised))
+            return fail(DDCN_ERR_LAUNCH, "gweight_16: cannot raise the LDS limit");
+        hipLaunchKernelGGL((gemm16_dma_kernel<T, 4, 4, 4>), g8, dim3(512), 4 * 32768, stream, b);
+    } else {
+        const dim3 gg((unsigned)tiles, (unsigned)(g.N * g.groups), nz);
+        hipLaunchKernelGGL((gemm16_dma_kernel<T, 4, 2>), gg, dim3(GT), 4 * 16384, stream, b);
+    }
+    if (int rc = check_launch("gemm_gweight_16")) return rc;
+    hipLaunchKernelGGL(gweight_finish_kernel, dim3((unsigned)((wtotal + 255) / 256)), dim3(256), 0, stream, gwp, gw, wtotal, Cg);
+    return check_launch("gweight_finish");
+}
+
+int launch_gweight_bf16(const void *x, const void *offset, const void *mask, const void *gout, float *gw, void *ws,
+                        const ddcn_geom &g, hipStream_t stream)
+{
+    return gweight_16<BF16>(x, offset, mask, gout, gw, ws, g, stream);
+}
+
+int launch_gweight_f16(const void *x, const void *offset, const void *mask, const void *gout, float *gw, void *ws,
+                       const ddcn_geom &g, hipStream_t stream)
+{
+    return gweight_16<F16>(x, offset, mask, gout, gw, ws, g, stream);
 }
 
 }  // namespace ddcn

@@ -98,6 +98,12 @@ size_t gcol16_workspace_bytes(const ddcn_geom &g);
 int gcol16_supported(const ddcn_geom &g);
 int launch_gemm_gcol_bf16(const void *weight, const void *gout, float *gcol, void *ws, const ddcn_geom &g, hipStream_t stream);
 int launch_gemm_gcol_f16(const void *weight, const void *gout, float *gcol, void *ws, const ddcn_geom &g, hipStream_t stream);
+size_t gweight16_workspace_bytes(const ddcn_geom &g);
+int gweight16_supported(const ddcn_geom &g);
+int launch_gweight_bf16(const void *x, const void *offset, const void *mask, const void *gout, float *gw, void *ws,
+                        const ddcn_geom &g, hipStream_t stream);
+int launch_gweight_f16(const void *x, const void *offset, const void *mask, const void *gout, float *gw, void *ws,
+                       const ddcn_geom &g, hipStream_t stream);
 
 int launch_forward_f16(const void *x, const void *weight, const void *bias, const void *offset, const void *mask,
                        void *out, void *ws, const ddcn_geom &g, hipStream_t stream);

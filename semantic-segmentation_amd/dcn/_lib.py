@@ -82,6 +82,10 @@ PROTOTYPES = {
     "ddcn_gemm_gcol_16_supported": [_G],
     "ddcn_gemm_gcol_bf16": [_P, _P, _P, _P, _SZ, _G, _P],
     "ddcn_gemm_gcol_f16": [_P, _P, _P, _P, _SZ, _G, _P],
+    "ddcn_gweight_16_workspace_bytes": [_G],
+    "ddcn_gweight_16_supported": [_G],
+    "ddcn_deform_conv_gweight_bf16": [_P, _P, _P, _P, _P, _P, _SZ, _G, _P],
+    "ddcn_deform_conv_gweight_f16": [_P, _P, _P, _P, _P, _P, _SZ, _G, _P],
     "ddcn_deform_psroi_pool_forward_f32": [_P, _P, _P, _P, _P, _RG, _P],
     "ddcn_deform_psroi_pool_backward_f32": [_P, _P, _P, _P, _P, _P, _P, _RG, _P],
     "ddcn_deform_psroi_pool_forward_f64": [_P, _P, _P, _P, _P, _RG, _P],
@@ -95,6 +99,7 @@ _RESTYPES = {
     "ddcn_static_scratch_bytes": _SZ,
     "ddcn_workspace_bytes_bf16": _SZ,
     "ddcn_gemm_gcol_16_workspace_bytes": _SZ,
+    "ddcn_gweight_16_workspace_bytes": _SZ,
     "ddcn_workspace_bytes_f64": _SZ,
 }
 

@@ -139,7 +139,8 @@ def _backward_saved(cd, input, weight, offset, mask, grad_output, cols, grad_inp
 
 
 # Training on bfloat16 / float16 tensors: forward on the native 16-bit kernels (16-bit columns, not kept), backward with
-# G2 on the 16-bit operands (ddcn_gemm_gcol_{bf16,f16}) and the scatter / im2col / G3 on the fp32 kernels.
+# G2 and G3 on the 16-bit operands (ddcn_gemm_gcol_{bf16,f16}; ddcn_deform_conv_gweight_{bf16,f16}, which recomputes the
+# columns in 16 bits as pixel octets) and the scatter on the fp32 kernel (fp32 column gradients, fp32 atomics).
 # DDCN_16BIT_TRAIN_NATIVE=0: everything on the fp32 kernels (convert in, compute, convert out), as in round 1.
 TRAIN16_NATIVE = os.environ.get("DDCN_16BIT_TRAIN_NATIVE", "1") != "0"
 
@@ -152,7 +153,9 @@ def _backward_16bit(dtype, input, offset, mask, weight, grad_output, with_bias, 
         return None
     p = _lib.ptr
     grad_output = grad_output.contiguous()
-    x32, off32, gout32 = input.float(), offset.float(), grad_output.float()
+    x32, off32 = input.float(), offset.float()
+    g3_16 = L.ddcn_gweight_16_supported(g) == 0
+    gout32 = grad_output.float() if (with_bias or not g3_16) else None
     mask32 = None if mask is None else mask.float()
     acts = [x32, off32] + ([mask32] if mask is not None else [])
     grads = _zeros_flat(acts)
@@ -169,8 +172,16 @@ def _backward_16bit(dtype, input, offset, mask, weight, grad_output, with_bias, 
         s = _lib.current_stream(input.device)
         _lib.check(gemm(p(weight), p(grad_output), p(ws), p(ws16), ws16_bytes, g, s))               # G2, 16-bit operands
         _lib.check(L.ddcn_col2im_coord_f32(p(ws), p(x32), p(off32), p(mask32), p(gx), p(goff), p(gmask), g, s))
-        _lib.check(L.ddcn_im2col_f32(p(x32), p(off32), p(mask32), p(ws), g, s))                       # columns for G3
-        _lib.check(L.ddcn_gemm_gweight_f32(p(gout32), p(ws), p(gw), g, s))
+        if g3_16:
+            # G3 on 16-bit operands: 16-bit columns as pixel octets (recomputed, never fp32), fp32 accumulation
+            wsw_bytes = L.ddcn_gweight_16_workspace_bytes(g)
+            wsw = ws.view(torch.uint8)[:wsw_bytes] if wsw_bytes <= ws_bytes else \
+                torch.empty(wsw_bytes, dtype=torch.uint8, device=input.device)
+            gw16 = L.ddcn_deform_conv_gweight_bf16 if dtype == torch.bfloat16 else L.ddcn_deform_conv_gweight_f16
+            _lib.check(gw16(p(input), p(offset), p(mask), p(grad_output), p(gw), p(wsw), wsw_bytes, g, s))
+        else:
+            _lib.check(L.ddcn_im2col_f32(p(x32), p(off32), p(mask32), p(ws), g, s))                   # columns for G3
+            _lib.check(L.ddcn_gemm_gweight_f32(p(gout32), p(ws), p(gw), g, s))
         if with_bias:
             _lib.check(L.ddcn_bias_grad_f32(p(gout32), p(gb), g, s))
     cv = lambda t: None if t is None else t.to(dtype)

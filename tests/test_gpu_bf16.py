@@ -207,6 +207,52 @@ def test_16bit_g2_entry_point_against_fp32_gemm():
     assert L.ddcn_gemm_gcol_16_supported(g) == -5 and L.ddcn_gemm_gcol_16_workspace_bytes(g) == 0
 
 
+@pytest.mark.parametrize("case", [
+    dict(N=2, C=32, Co=72, H=21, W=45, dil=2, groups=1, dg=4, mod=True, spread=2.0, half=False),
+    dict(N=1, C=64, Co=32, H=19, W=37, dil=1, groups=2, dg=2, mod=False, spread=2.0, half=False),
+    dict(N=2, C=16, Co=264, H=9, W=70, dil=3, groups=1, dg=1, mod=True, spread=9.0, half=True),   # most samples escape
+], ids=["dg4_mod", "groups2_plain", "wide_offsets_f16"])
+def test_16bit_g3_entry_point_against_fp32_kernels(case):
+    """ddcn_deform_conv_gweight_{bf16,f16} through the C ABI against the fp32 chain (im2col_f32 + gemm_gweight_f32) on the
+    same 16-bit-representable inputs: the difference is one rounding of every column value to 16 bits (2^-9 / 2^-11
+    relative) inside a sum over N * P pixels.  Also: the result is ADDED to grad_weight."""
+    L = _lib.lib()
+    c = case
+    dt = torch.float16 if c["half"] else torch.bfloat16
+    rng = np.random.default_rng(c["C"] + c["H"])
+    N, C, Co, H, W, d = c["N"], c["C"], c["Co"], c["H"], c["W"], c["dil"]
+    g = _lib.Geom(N, C, H, W, Co, 3, 3, 1, 1, d, d, d, d, c["groups"], c["dg"], H, W)
+    assert L.ddcn_gweight_16_supported(g) == 0
+    r16 = lambda a: torch.from_numpy(a.astype(np.float32)).to(DEV).to(dt)
+    x = r16(rng.standard_normal((N, C, H, W)))
+    off = r16(rng.standard_normal((N, c["dg"] * 18, H, W)) * c["spread"])
+    mask = r16(rng.random((N, c["dg"] * 9, H, W))) if c["mod"] else None
+    gout = r16(rng.standard_normal((N, Co, H, W)))
+    s = _lib.current_stream(torch.device(DEV))
+    p = _lib.ptr
+    # fp32 chain on the same values
+    x32, off32, gout32 = x.float(), off.float(), gout.float()
+    m32 = mask.float() if c["mod"] else None
+    nb = L.ddcn_workspace_bytes(g)
+    cols = torch.empty(nb // 4, device=DEV)
+    ref = torch.zeros(Co, C // c["groups"], 3, 3, device=DEV)
+    _lib.check(L.ddcn_im2col_f32(p(x32), p(off32), p(m32), p(cols), g, s))
+    _lib.check(L.ddcn_gemm_gweight_f32(p(gout32), p(cols), p(ref), g, s))
+    nbw = L.ddcn_gweight_16_workspace_bytes(g)
+    assert nbw > 0
+    ws = torch.empty(nbw, dtype=torch.uint8, device=DEV)
+    got = torch.full_like(ref, 0.5)                       # accumulated into
+    fn = L.ddcn_deform_conv_gweight_f16 if c["half"] else L.ddcn_deform_conv_gweight_bf16
+    _lib.check(fn(p(x), p(off), p(mask), p(gout), p(got), p(ws), nbw, g, s))
+    torch.cuda.synchronize()
+    a, b = (got - 0.5).cpu().numpy(), ref.cpu().numpy()
+    assert np.isfinite(a).all()
+    assert cases.relerr(a, b) <= (2e-3 if c["half"] else 1e-2), cases.relerr(a, b)
+    # too small a workspace, NULL operands
+    assert fn(p(x), p(off), p(mask), p(gout), p(got), p(ws), nbw - 1, g, s) == -3
+    assert fn(None, p(off), p(mask), p(gout), p(got), p(ws), nbw, g, s) == -1
+
+
 def test_bf16_uncovered_geometries_use_fp32_kernels():
     c = BF16_CASES[0]
     x, off, mask, w, bias, Ho, Wo = _inputs(c, seed=3)
