@@ -1080,21 +1080,29 @@ int launch_gemm_gcol_f16(const void *weight, const void *gout, float *gcol, void
 //   C = fp32 partial sums added into gw'[Co][tap][Cg] (atomics: images x K splits), then gw[o][c][tap] += gw'[o][tap][c].
 namespace {
 
-__global__ __launch_bounds__(256) void gout_pixblock_kernel(const bf16_t *gout, bf16_t *ap, long total, int Co, int Cog,
+// one thread per 8 consecutive k (= 8 pixels of one tile row): eight 2-byte loads, one 16-byte store
+__global__ __launch_bounds__(256) void gout_pixblock_kernel(const bf16_t *gout, u32x4 *ap, long total8, int Co, int Cog,
                                                            int KT, int tiles_w, int Ho, int Wo)
 {
     const long i = (long)blockIdx.x * 256 + threadIdx.x;
-    if (i >= total) return;
-    const int k32 = (int)(i & 31);
-    long rest = i >> 5;
+    if (i >= total8) return;
+    const int k8 = (int)(i & 3);
+    long rest = i >> 2;
     const int o = (int)(rest % Cog); rest /= Cog;
     const int kt = (int)(rest % KT); rest /= KT;
     const int groups = Co / Cog;
     const int grp = (int)(rest % groups);
     const long n = rest / groups;
-    const int idx = kt * 32 + k32, tile = idx >> 8, t = idx & 255;
-    const int ho = (tile / tiles_w) * TH + (t >> 5), wo = (tile % tiles_w) * TW + (t & 31);
-    ap[i] = (ho < Ho && wo < Wo) ? gout[((n * Co + (long)grp * Cog + o) * Ho + ho) * Wo + wo] : (bf16_t)0;
+    const int idx = kt * 32 + k8 * 8, tile = idx >> 8, t = idx & 255;
+    const int ho = (tile / tiles_w) * TH + (t >> 5), wo0 = (tile % tiles_w) * TW + (t & 31);
+    const bf16_t *src = gout + ((n * Co + (long)grp * Cog + o) * Ho + min(ho, Ho - 1)) * Wo;
+    unsigned short v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = (ho < Ho && wo0 + e < Wo) ? src[wo0 + e] : (unsigned short)0;
+    u32x4 r;
+    r.x = v[0] | ((unsigned)v[1] << 16); r.y = v[2] | ((unsigned)v[3] << 16);
+    r.z = v[4] | ((unsigned)v[5] << 16); r.w = v[6] | ((unsigned)v[7] << 16);
+    ap[i] = r;
 }
 
 __global__ __launch_bounds__(256) void zero_f32_kernel(float *p, long n)
@@ -1182,8 +1190,8 @@ static int gweight_16(const void *x, const void *offset, const void *mask, const
     // A: grad_out in the same pixel order, blocked; the partial result starts at zero
     const int KT = (int)(pl.kpix / 32);
     const long atotal = (long)g.N * g.Co * pl.kpix;
-    hipLaunchKernelGGL(gout_pixblock_kernel, dim3((unsigned)((atotal + 255) / 256)), dim3(256), 0, stream,
-                       (const bf16_t *)gout, ap, atotal, g.Co, Cog, KT, a.tiles_w, g.Ho, g.Wo);
+    hipLaunchKernelGGL(gout_pixblock_kernel, dim3((unsigned)((atotal / 8 + 255) / 256)), dim3(256), 0, stream,
+                       (const bf16_t *)gout, (u32x4 *)ap, atotal / 8, g.Co, Cog, KT, a.tiles_w, g.Ho, g.Wo);
     const long wtotal = (long)g.Co * Kg;
     hipLaunchKernelGGL(zero_f32_kernel, dim3((unsigned)((wtotal + 255) / 256)), dim3(256), 0, stream, gwp, wtotal);
     if (int rc = check_launch("gout_pixblock")) return rc;

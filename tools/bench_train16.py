@@ -34,5 +34,5 @@ for dt in (torch.bfloat16, torch.float16):
             step()
         b.record()
         b.synchronize()
-        print("%-9s %-40s %.3f ms per fwd+bwd" % (str(dt).split(".")[1], "native fwd + 16-bit G2" if native else
+        print("%-9s %-40s %.3f ms per fwd+bwd" % (str(dt).split(".")[1], "native fwd, 16-bit G2 and G3" if native else
                                                   "fp32 kernels (convert in / out)", a.elapsed_time(b) / 20), flush=True)

@@ -18,7 +18,7 @@ KERNELS = {   # bench.py stage name -> substring of the kernel's name
     "im2col": "im2col_tile_kernel<true",
     "gemm_out": "gemm_f32_mfma<true, false, false>",
     "gemm_gcol": "gemm_f32_mfma<false, false, false>",
-    "col2im_coord": "col2im_coord_tile9_kernel<true",
+    "col2im_coord": "col2im_coord_tile9_adaptive_kernel<true",
     "gemm_gweight": "gemm_f32_mfma<true, true, true>",
 }
 
