@@ -85,7 +85,32 @@ def pipelined():
     main.wait_event(ev2)
 
 
-for name, fn in (("sequential", seq), ("pipelined per image", pipelined), ("G3 on side stream beside scatter", g3_beside_scatter),
+out = torch.empty(2, 512, 97, 97, device=dev)
+cols_img = cols.view(2, -1)
+
+
+def fwd_seq():
+    _lib.check(L.ddcn_im2col_f32(p(x), p(offset), p(mask), p(cols), g, sm))
+    _lib.check(L.ddcn_gemm_out_f32(p(weight), p(cols), None, p(out), g, sm))
+
+
+def fwd_pipelined():
+    """im2col of image n+1 on the side stream beside G1 of image n."""
+    evs = []
+    ev0 = torch.cuda.Event()
+    ev0.record(main)
+    side.wait_event(ev0)
+    for n in range(2):
+        _lib.check(L.ddcn_im2col_f32(off_ptr(x, n), off_ptr(offset, n), off_ptr(mask, n), off_ptr(cols_img, n), g1, ss))
+        ev = torch.cuda.Event()
+        ev.record(side)
+        evs.append(ev)
+    for n in range(2):
+        main.wait_event(evs[n])
+        _lib.check(L.ddcn_gemm_out_f32(p(weight), off_ptr(cols_img, n), None, off_ptr(out, n), g1, sm))
+
+
+for name, fn in (("forward sequential", fwd_seq), ("forward, im2col(n+1) beside G1(n)", fwd_pipelined), ("sequential", seq), ("pipelined per image", pipelined), ("G3 on side stream beside scatter", g3_beside_scatter),
                  ("scatter on side stream beside G3", scatter_first_then_g3_side)):
     for _ in range(5):
         fn()
