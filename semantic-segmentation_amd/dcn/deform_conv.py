@@ -169,15 +169,30 @@ def _backward_16bit(dtype, input, offset, mask, weight, grad_output, with_bias, 
     ws16 = torch.empty(ws16_bytes // 2, dtype=dtype, device=input.device)
     gemm = L.ddcn_gemm_gcol_bf16 if dtype == torch.bfloat16 else L.ddcn_gemm_gcol_f16
     with torch.cuda.device(input.device):
+        main = torch.cuda.current_stream(input.device)
         s = _lib.current_stream(input.device)
+        gw16 = L.ddcn_deform_conv_gweight_bf16 if dtype == torch.bfloat16 else L.ddcn_deform_conv_gweight_f16
+        two = g3_16 and TWO_STREAM_BACKWARD and not torch.cuda.is_current_stream_capturing()
+        if two:
+            # grad_weight needs only the inputs and grad_out: its chain (16-bit im2col, grad_out gather, GEMM) runs on the
+            # side stream beside G2 and the LDS-atomic-bound scatter, in a workspace of its own
+            side, fork, join = _side_stream(input.device)
+            wsw_bytes = L.ddcn_gweight_16_workspace_bytes(g)
+            wsw = torch.empty(wsw_bytes, dtype=torch.uint8, device=input.device)
+            fork.record(main)
+            side.wait_event(fork)
+            _lib.check(gw16(p(input), p(offset), p(mask), p(grad_output), p(gw), p(wsw), wsw_bytes, g,
+                            ctypes.c_void_p(side.cuda_stream)))
+            join.record(side)
         _lib.check(gemm(p(weight), p(grad_output), p(ws), p(ws16), ws16_bytes, g, s))               # G2, 16-bit operands
         _lib.check(L.ddcn_col2im_coord_f32(p(ws), p(x32), p(off32), p(mask32), p(gx), p(goff), p(gmask), g, s))
-        if g3_16:
+        if two:
+            main.wait_event(join)
+        elif g3_16:
             # G3 on 16-bit operands: 16-bit columns as pixel octets (recomputed, never fp32), fp32 accumulation
             wsw_bytes = L.ddcn_gweight_16_workspace_bytes(g)
             wsw = ws.view(torch.uint8)[:wsw_bytes] if wsw_bytes <= ws_bytes else \
                 torch.empty(wsw_bytes, dtype=torch.uint8, device=input.device)
-            gw16 = L.ddcn_deform_conv_gweight_bf16 if dtype == torch.bfloat16 else L.ddcn_deform_conv_gweight_f16
             _lib.check(gw16(p(input), p(offset), p(mask), p(grad_output), p(gw), p(wsw), wsw_bytes, g, s))
         else:
             _lib.check(L.ddcn_im2col_f32(p(x32), p(off32), p(mask32), p(ws), g, s))                   # columns for G3
