@@ -60,11 +60,12 @@ def _check_against_fp32_oracle(x, w, off, mask, gout, dil, dg):
     assert not bad.any(), "%d grad_offset elements differ (first at %s)" % (bad.sum(), np.argwhere(bad)[:3].tolist())
 
 
-@pytest.mark.parametrize("sigma", [2.0, 8.0], ids=["sigma2", "sigma8"])
+@pytest.mark.parametrize("sigma", [2.0, 5.0, 8.0], ids=["sigma2", "sigma5", "sigma8"])   # sigma5: narrow and wide tiles mix
 @pytest.mark.parametrize("shape", [
     dict(N=2, C=64, Co=48, H=33, W=29, dil=2, dg=1),      # LDS-tiled 3x3 kernels, escapees at sigma 8
     dict(N=1, C=32, Co=32, H=40, W=52, dil=4, dg=4),      # deformable groups
-], ids=["c64_33x29_d2", "c32_40x52_d4_dg4"])
+    dict(N=1, C=16, Co=24, H=45, W=37, dil=6, dg=2),      # dilation 6: the planner's own margin drops below 6
+], ids=["c64_33x29_d2", "c32_40x52_d4_dg4", "c16_45x37_d6_dg2"])
 def test_raw_offsets_medium_against_fp32_oracle(shape, sigma):
     t = _raw_inputs(shape["N"], shape["C"], shape["Co"], shape["H"], shape["W"], shape["dil"], shape["dg"], sigma,
                     seed=int(sigma) * 10 + shape["C"])
