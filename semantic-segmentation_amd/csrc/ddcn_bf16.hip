@@ -112,6 +112,7 @@ struct Bf16Args {
     int kt_per;           // K tiles (32 k) per split; blockIdx.z = split
     // im2col with pixel octets (G3 of the 16-bit backward): col[n][tiles*32][Ktot][8], pixel order = (tile, lane)
     int pixoct;
+    int pp_prio;          // experiment: s_setprio level of the MFMA phase in the ping-pong schedule
 };
 
 constexpr int IT = 256;  // im2col threads
@@ -620,7 +621,12 @@ constexpr unsigned wait_vm_lgkm0(int vm) { return (unsigned)((vm & 0xF) | ((vm >
 
 // NWN = wave columns: 2 -> 4 waves, 128 pixels per tile; 4 -> 8 waves, 256 pixels (with MI = 4 a 256x256 tile: 128
 // flop per operand byte fetched through L1/L2 instead of 85, one workgroup of two waves per SIMD on a CU).
-template <typename T, int NS, int MI, int NWN = 2>
+// PP (256 x 256 tiles only, opt-in): the two row groups of the workgroup -- one wave of each per SIMD -- alternate between
+// an MFMA phase (all 32 MFMAs of a K step) and a memory phase (DMA requests of a later tile, all 12 fragment reads of the
+// next), two barriers per K step.  The idea: in the lockstep schedule both waves of a SIMD issue their DMA requests (60-180
+// cycles each) at the same time, right after the step's barrier.  Measured: 11 % SLOWER than lockstep -- one wave alone
+// does not keep the matrix pipe as busy as two interleaved ones, and the second barrier costs more than the overlap gains.
+template <typename T, int NS, int MI, int NWN = 2, bool PP = false>
 __global__ __launch_bounds__(128 * NWN, NWN == 4 ? 1 : (MI == 4 ? 2 : (NS == 2 ? 4 : (NS == 3 ? 3 : 2))))
 void gemm16_dma_kernel(const Bf16Args a)
 {
@@ -756,11 +762,72 @@ void gemm16_dma_kernel(const Bf16Args a)
     wait_all_but(min(NS - 1, ntiles - 1));
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
-    read_b(0, fbx);
-    read_a(0, 0, fa0);
-    for (int kt = 0; kt < ntiles; kt += 2) {
-        step(kt, fbx, fby);
-        if (kt + 1 < ntiles) step(kt + 1, fby, fbx);
+    if constexpr (PP) {
+        static_assert(!PP || (NWN == 4 && MI == 4 && NS == 4), "ping-pong: the 8-wave 256 x 256 tile");
+        // Tile T is complete in LDS once EVERY wave has waited for its own pieces of T and a barrier has passed.
+        //   phase P0(kt): group 0 MFMAs of tile kt         | group 1: request tile kt-1+NS, read fragments of tile kt
+        //   phase P1(kt): group 1 MFMAs of tile kt         | group 0: request tile kt+NS,   read fragments of tile kt+1
+        // Both groups wait for their pieces of tile kt+1 before the barrier that ends P0(kt) (group 0 reads it in P1(kt),
+        // group 1 in P0(kt+1)).  A stage is requested again only after both groups have read it: tile kt's stage by group 0
+        // in P1(kt) (its own read: P1(kt-1); group 1's: P0(kt), complete at that phase's barrier), by group 1 in P0(kt+1).
+        u32x4 fa[2 * MI], fb[4];
+        auto read_all = [&](int kt) {
+            const u32x4 *As = ring + (kt % NS) * STAGE;
+            const u32x4 *Bs = As + BMK * 4;
+#pragma unroll
+            for (int i = 0; i < 2 * MI; ++i) {
+                const int row = wm * (MI * 32) + i * 16 + r16;
+                fa[i] = As[row * 4 + (kc ^ a_swizzle(row))];
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) fb[j] = Bs[kc * BNW + wn * 64 + j * 16 + r16];
+        };
+        auto mfma_all = [&]() {
+            if (a.pp_prio) __builtin_amdgcn_s_setprio(2);
+#pragma unroll
+            for (int i = 0; i < 2 * MI; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = T::mfma16(fa[i], fb[j], acc[i][j]);
+            __builtin_amdgcn_sched_barrier(0);
+            if (a.pp_prio) __builtin_amdgcn_s_setprio(0);
+        };
+        // own pieces of tile `need` have landed (my youngest request is tile `last`); always drains this wave's LDS reads
+        auto wait_tile = [&](int need, int last) {
+            const int younger = min(last, ntiles - 1) - need;
+            if (need < ntiles) wait_all_but(max(younger, 0));
+            else __builtin_amdgcn_s_waitcnt(wait_vm_lgkm0(63));
+        };
+        if (wm == 0) read_all(0);
+        for (int kt = 0; kt < ntiles; ++kt) {
+            if (wm == 0) {
+                mfma_all();
+            } else {
+                if (kt >= 1 && kt - 1 + NS < ntiles) request(kt - 1 + NS);
+                read_all(kt);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            wait_tile(kt + 1, kt - 1 + NS);
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            if (wm == 1) {
+                mfma_all();
+            } else {
+                if (kt + NS < ntiles) request(kt + NS);
+                if (kt + 1 < ntiles) read_all(kt + 1);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    } else {
+        read_b(0, fbx);
+        read_a(0, 0, fa0);
+        for (int kt = 0; kt < ntiles; kt += 2) {
+            step(kt, fbx, fby);
+            if (kt + 1 < ntiles) step(kt + 1, fby, fbx);
+        }
     }
 
     // lane l holds rows 4*(l/16) + e, column l % 16 of each 16 x 16 tile
@@ -862,6 +929,29 @@ static void run_bf16_tile(const Bf16Args &a, const dim3 &grid, hipStream_t strea
     }
 }
 
+// 256 x 256 tiles.  DDCN_BF16_GEMM_PP=1 / 2 selects the phase-split (ping-pong) schedule, without / with a raised priority
+// for the MFMA phase: measured 165-168 us against 149-152 us for the default lockstep schedule on layer4 of config 5
+// (profiles/r02c_bf16_pingpong.txt), so it stays an experiment.
+template <typename T>
+static int launch_gemm16_sq(const dim3 &grid, hipStream_t stream, const Bf16Args &a, const char *what)
+{
+    const char *e = getenv("DDCN_BF16_GEMM_PP");
+    if (e && atoi(e) > 0) {
+        static std::atomic<uint64_t> raised{0};
+        if (!raise_lds_limit((const void *)gemm16_dma_kernel<T, 4, 4, 4, true>, 4 * 32768, raised))
+            return fail(DDCN_ERR_LAUNCH, "%s: cannot raise the LDS limit", what);
+        Bf16Args b = a;
+        b.pp_prio = atoi(e) - 1;              // DDCN_BF16_GEMM_PP=1: no priority change, 2: MFMA phase at priority 2
+        hipLaunchKernelGGL((gemm16_dma_kernel<T, 4, 4, 4, true>), grid, dim3(512), 4 * 32768, stream, b);
+    } else {
+        static std::atomic<uint64_t> raised{0};
+        if (!raise_lds_limit((const void *)gemm16_dma_kernel<T, 4, 4, 4>, 4 * 32768, raised))
+            return fail(DDCN_ERR_LAUNCH, "%s: cannot raise the LDS limit", what);
+        hipLaunchKernelGGL((gemm16_dma_kernel<T, 4, 4, 4>), grid, dim3(512), 4 * 32768, stream, a);
+    }
+    return DDCN_OK;
+}
+
 // Operand placement of the round-1 forward GEMM: W'' slabs per group, columns [n][K/8][P][8] with the groups splitting k
 static void gemm_operands_forward(Bf16Args &a)
 {
@@ -935,10 +1025,7 @@ static int forward_16(const void *x, const void *weight, const void *bias, const
     const int mi = em ? atoi(em) : ((a.Cog >= 192 && tiles_sq >= 256) ? 8 : (a.Cog >= 192 && tiles256 >= 512) ? 4 : 2);
     if (dma_ok && mi == 8 && stages >= 2) {
         const dim3 g8((unsigned)((a.Cog + 255) / 256 * ((a.P + 255) / 256)), (unsigned)(g.N * g.groups));
-        static std::atomic<uint64_t> raised{0};   // 4 stages x 32 KiB
-        if (!raise_lds_limit((const void *)gemm16_dma_kernel<T, 4, 4, 4>, 4 * 32768, raised))
-            return fail(DDCN_ERR_LAUNCH, "gemm_16: cannot raise the LDS limit");
-        hipLaunchKernelGGL((gemm16_dma_kernel<T, 4, 4, 4>), g8, dim3(512), 4 * 32768, stream, a);
+        if (int rc = launch_gemm16_sq<T>(g8, stream, a, "gemm_16")) return rc;   // 4 stages x 32 KiB
     } else if (dma_ok && mi == 4 && stages >= 2) {
         const dim3 g4((unsigned)((a.Cog + 255) / 256 * a.tiles_n), (unsigned)(g.N * g.groups));
         static std::atomic<uint64_t> raised{0};   // 3 stages x 24 KiB: above the 64 KiB default
@@ -1049,10 +1136,7 @@ static int gemm_gcol_16(const void *weight, const void *gout, float *gcol, void 
     const long tiles_sq = (long)((M + 255) / 256) * ((P + 255) / 256) * g.N * g.groups;
     if (M >= 192 && tiles_sq >= 256) {
         const dim3 g8((unsigned)((M + 255) / 256 * ((P + 255) / 256)), (unsigned)(g.N * g.groups));
-        static std::atomic<uint64_t> raised{0};
-        if (!raise_lds_limit((const void *)gemm16_dma_kernel<T, 4, 4, 4>, 4 * 32768, raised))
-            return fail(DDCN_ERR_LAUNCH, "gemm_gcol_16: cannot raise the LDS limit");
-        hipLaunchKernelGGL((gemm16_dma_kernel<T, 4, 4, 4>), g8, dim3(512), 4 * 32768, stream, a);
+        if (int rc = launch_gemm16_sq<T>(g8, stream, a, "gemm_gcol_16")) return rc;
     } else {
         const dim3 gg((unsigned)((M + 127) / 128 * ((P + 127) / 128)), (unsigned)(g.N * g.groups));
         hipLaunchKernelGGL((gemm16_dma_kernel<T, 4, 2>), gg, dim3(GT), 4 * 16384, stream, a);
@@ -1214,10 +1298,7 @@ static int gweight_16(const void *x, const void *offset, const void *mask, const
     const unsigned nz = (unsigned)((KT + b.kt_per - 1) / b.kt_per);
     if (sq) {
         const dim3 g8((unsigned)tiles, (unsigned)(g.N * g.groups), nz);
-        static std::atomic<uint64_t> raised{0};
-        if (!raise_lds_limit((const void *)gemm16_dma_kernel<T, 4, 4, 4>, 4 * 32768, raised))
-            return fail(DDCN_ERR_LAUNCH, "gweight_16: cannot raise the LDS limit");
-        hipLaunchKernelGGL((gemm16_dma_kernel<T, 4, 4, 4>), g8, dim3(512), 4 * 32768, stream, b);
+        if (int rc = launch_gemm16_sq<T>(g8, stream, b, "gweight_16")) return rc;
     } else {
         const dim3 gg((unsigned)tiles, (unsigned)(g.N * g.groups), nz);
         hipLaunchKernelGGL((gemm16_dma_kernel<T, 4, 2>), gg, dim3(GT), 4 * 16384, stream, b);

@@ -84,16 +84,18 @@ def _exact_bf16_columns_result(c, x, off, mask, w, bias, Ho, Wo):
     return out.reshape(c["N"], c["Co"], Ho, Wo)
 
 
-@pytest.mark.parametrize("tiled", ["1", "0", "mi4", "mi8", "regstage"],
-                         ids=["lds_tiled", "direct", "gemm_256_rows", "gemm_256x256", "gemm_regstage"])
+@pytest.mark.parametrize("tiled", ["1", "0", "mi4", "mi8", "mi8pp", "regstage"],
+                         ids=["lds_tiled", "direct", "gemm_256_rows", "gemm_256x256", "gemm_256x256_pingpong", "gemm_regstage"])
 @pytest.mark.parametrize("c", BF16_CASES, ids=lambda c: c["name"])
 def test_native_bf16_forward_matches_oracle(c, tiled, fmt, monkeypatch):
     dtype, ulp, e2e_tol = fmt
     # read by the library at every call: im2col kernel (LDS-tiled / direct gather) and GEMM variant (LDS-DMA ring with
     # 128- or 256-row tiles or 256x256 tiles of 8 waves, register-staged)
     monkeypatch.setenv("DDCN_BF16_TILE", "0" if tiled == "0" else "1")
-    if tiled in ("mi4", "mi8"):
+    if tiled in ("mi4", "mi8", "mi8pp"):
         monkeypatch.setenv("DDCN_BF16_GEMM_MI", tiled[2])
+    if tiled == "mi8pp":
+        monkeypatch.setenv("DDCN_BF16_GEMM_PP", "2")     # the opt-in phase-split schedule of the 256 x 256 tile
     if tiled == "regstage":
         monkeypatch.setenv("DDCN_BF16_GEMM_STAGES", "0")
     x, off, mask, w, bias, Ho, Wo = _inputs(c)
