@@ -33,6 +33,7 @@
 #include <stdlib.h>
 
 #include <algorithm>
+#include <type_traits>
 
 namespace ddcn {
 namespace {
@@ -236,7 +237,9 @@ constexpr int TH = 8, TW = 32;
 
 // grid = (tiles * cgroups, 1, N); dynamic LDS = 2 buffers of RS cells x 16 bytes
 // PAIR: the patch is staged two cells per 4-byte load (W even, patch columns start on an even image column)
-template <typename T, bool MOD, int NCELL, bool PAIR>
+// PIXOCT: pixel-octet columns (the B operand of G3) instead of k-octets; a template parameter because the two store paths
+// in one body cost 60 VGPRs (and with them the room for the second staging register set)
+template <typename T, bool MOD, int NCELL, bool PAIR, bool PIXOCT = false>
 __global__ __launch_bounds__(IT, 2) void im2col_bf16_tile_kernel(const Bf16Args a)
 {
     extern __shared__ u32x4 patch[];
@@ -303,8 +306,15 @@ __global__ __launch_bounds__(IT, 2) void im2col_bf16_tile_kernel(const Bf16Args 
     // right after the loads would make the compiler wait for the loads before the sampling they are meant to overlap.
     // PAIR: 8 dwords per unit (one per channel, two cells each); else 8 halfwords per cell, packed late as well.
     constexpr int NSTG = PAIR ? NUNIT * 8 : NCELL * 8;
-    unsigned stg[NSTG];
-    auto stage_load = [&](int c0) {   // c0 relative to c_begin
+    // DEEP: a second staging register set, so that the loads of octet oc+2 are issued when the sampling of octet oc starts
+    // and have two iterations to arrive (counters on layer 4 of config 5: 43 % of the wave cycles are waits -- an octet's
+    // sampling, 1.2 us, is shorter than a load's round trip under load).  Built and measured with pair staging (+32
+    // registers): the two-octet loop body needs 253-256 VGPRs and spills 70-170 of them, layer 4 took 221 us instead of
+    // 130 (profiles/r02c_bf16_pingpong.txt).  Off; the structure stays for a version that keeps the per-tap state in LDS.
+    constexpr bool DEEP = false;
+    unsigned stgs[DEEP ? 2 : 1][NSTG];
+    auto stage_load = [&](int c0, auto SEL) {   // c0 relative to c_begin; SEL: which register set
+        unsigned (&stg)[NSTG] = stgs[decltype(SEL)::value];
         if constexpr (PAIR) {
 #pragma unroll
             for (int j = 0; j < NUNIT; ++j)
@@ -319,7 +329,8 @@ __global__ __launch_bounds__(IT, 2) void im2col_bf16_tile_kernel(const Bf16Args 
                     stg[j * 8 + c] = soff[j] >= 0 ? (unsigned)xb[(long)(c0 + c) * HW + soff[j]] : 0u;
         }
     };
-    auto stage_store = [&](u32x4 *buf) {
+    auto stage_store = [&](u32x4 *buf, auto SEL) {
+        const unsigned (&stg)[NSTG] = stgs[decltype(SEL)::value];
         if constexpr (PAIR) {
 #pragma unroll
             for (int j = 0; j < NUNIT; ++j) {
@@ -353,10 +364,15 @@ __global__ __launch_bounds__(IT, 2) void im2col_bf16_tile_kernel(const Bf16Args 
         }
     };
 
-    stage_load(0);
-    stage_store(buf0);
-    __syncthreads();
     const int nocts = a.CG / 8;
+    typedef std::integral_constant<int, 0> S0;
+    typedef std::integral_constant<int, DEEP ? 1 : 0> S1;
+    stage_load(0, S0{});
+    stage_store(buf0, S0{});
+    __syncthreads();
+    if constexpr (DEEP) {
+        if (nocts > 1) stage_load(8, S1{});
+    }
     u32x4 *colp = (u32x4 *)a.col + ((long)n * a.KO + (long)(c_begin / 8) * 9) * a.P + p;
     // Pixel-octet mode (the B operand of G3, which contracts over pixels): col[n][pixel octet][row][8 pixels] with the
     // pixels in (tile, lane) order -- lanes outside the map are zero columns -- and rows ordered (group, tap, channel), so
@@ -389,11 +405,16 @@ __global__ __launch_bounds__(IT, 2) void im2col_bf16_tile_kernel(const Bf16Args 
         dst[0] = (bf16_t)o.x; dst[8] = (bf16_t)(o.x >> 16); dst[16] = (bf16_t)o.y; dst[24] = (bf16_t)(o.y >> 16);
         dst[32] = (bf16_t)o.z; dst[40] = (bf16_t)(o.z >> 16); dst[48] = (bf16_t)o.w; dst[56] = (bf16_t)(o.w >> 16);
     };
-    for (int oc = 0; oc < nocts; ++oc) {
+    // one octet: rn holds (or receives) the patch of octet oc+1, rf is free for octet oc+2 (DEEP)
+    auto octet = [&](int oc, auto rn, auto rf) __attribute__((always_inline)) {
         const u32x4 *cur = (oc & 1) ? buf1 : buf0;
         u32x4 *nxt = (oc & 1) ? buf0 : buf1;
-        if (oc + 1 < nocts) stage_load((oc + 1) * 8);
-        if (a.pixoct) {
+        if constexpr (DEEP) {
+            if (oc + 2 < nocts) stage_load((oc + 2) * 8, rf);
+        } else {
+            if (oc + 1 < nocts) stage_load((oc + 1) * 8, rn);
+        }
+        if constexpr (PIXOCT) {
 #pragma unroll
             for (int k = 0; k < 9; ++k) {
                 const bool use = live && cell[k] >= 0;         // escapees are filled in by the second pass, the rest is zero
@@ -424,8 +445,16 @@ __global__ __launch_bounds__(IT, 2) void im2col_bf16_tile_kernel(const Bf16Args 
                 colp[((long)oc * 9 + k) * a.P] = o;
             }
         }
-        if (oc + 1 < nocts) stage_store(nxt);
+        if (oc + 1 < nocts) stage_store(nxt, rn);
         __syncthreads();
+    };
+    if constexpr (DEEP) {
+        for (int oc = 0; oc < nocts; oc += 2) {
+            octet(oc, S1{}, S0{});
+            if (oc + 1 < nocts) octet(oc + 1, S0{}, S1{});
+        }
+    } else {
+        for (int oc = 0; oc < nocts; ++oc) octet(oc, S0{}, S0{});
     }
     // Second pass: samples whose corners leave the staged patch, from global memory with the reference's guards.
     // Few lanes hold one (0.5 % of the samples at sigma 2) but almost every wave does, and a wave that walks its own
@@ -448,14 +477,14 @@ __global__ __launch_bounds__(IT, 2) void im2col_bf16_tile_kernel(const Bf16Args 
             const unsigned slot = atomicAdd(cnt, 1u);
             if (slot < cap) {
                 u32x4 e;
-                e.x = (unsigned)(a.pixoct ? t : p) | ((unsigned)k << 27);
+                e.x = (unsigned)(PIXOCT ? t : p) | ((unsigned)k << 27);
                 e.y = __float_as_uint(h); e.z = __float_as_uint(w); e.w = __float_as_uint(m);
                 patch[1 + slot] = e;
             } else {
 #pragma unroll 2
                 for (int oc = 0; oc < nocts; ++oc) {
                     const u32x4 o = sample_octet_global<T>(xb + (long)oc * 8 * HW, HW, a.H, a.W, h, w, m);
-                    if (a.pixoct) pixoct_put(oc, k, t, o);
+                    if (PIXOCT) pixoct_put(oc, k, t, o);
                     else colp[((long)oc * 9 + k) * a.P] = o;
                 }
             }
@@ -470,7 +499,7 @@ __global__ __launch_bounds__(IT, 2) void im2col_bf16_tile_kernel(const Bf16Args 
         const int ep = (int)(e.x & 0x7ffffffu), k = (int)(e.x >> 27);
         const u32x4 o = sample_octet_global<T>(xb + (long)oc * 8 * HW, HW, a.H, a.W, __uint_as_float(e.y),
                                                __uint_as_float(e.z), __uint_as_float(e.w));
-        if (a.pixoct) pixoct_put(oc, k, ep, o);
+        if (PIXOCT) pixoct_put(oc, k, ep, o);
         else colg[((long)oc * 9 + k) * a.P + ep] = o;
     }
 }
@@ -918,15 +947,21 @@ static void run_bf16_tile(const Bf16Args &a, const dim3 &grid, hipStream_t strea
 {
     const size_t lds = (size_t)2 * a.RS * 16 + (a.pixoct ? IT * 16 : 0);   // + the waves' transposition slots
     const int ncell = (a.RS + IT - 1) / IT;
+#define DDCN_I16_LAUNCH(NC, PR)                                                                                       \
+    do {                                                                                                              \
+        if (a.pixoct) hipLaunchKernelGGL((im2col_bf16_tile_kernel<T, MOD, NC, PR, true>), grid, dim3(IT), lds, stream, a);   \
+        else hipLaunchKernelGGL((im2col_bf16_tile_kernel<T, MOD, NC, PR, false>), grid, dim3(IT), lds, stream, a);    \
+    } while (0)
     if (a.pair) {
-        if (ncell <= 4) hipLaunchKernelGGL((im2col_bf16_tile_kernel<T, MOD, 4, true>), grid, dim3(IT), lds, stream, a);
-        else if (ncell <= 6) hipLaunchKernelGGL((im2col_bf16_tile_kernel<T, MOD, 6, true>), grid, dim3(IT), lds, stream, a);
-        else hipLaunchKernelGGL((im2col_bf16_tile_kernel<T, MOD, 8, true>), grid, dim3(IT), lds, stream, a);
+        if (ncell <= 4) DDCN_I16_LAUNCH(4, true);
+        else if (ncell <= 6) DDCN_I16_LAUNCH(6, true);
+        else DDCN_I16_LAUNCH(8, true);
     } else {
-        if (ncell <= 4) hipLaunchKernelGGL((im2col_bf16_tile_kernel<T, MOD, 4, false>), grid, dim3(IT), lds, stream, a);
-        else if (ncell <= 6) hipLaunchKernelGGL((im2col_bf16_tile_kernel<T, MOD, 6, false>), grid, dim3(IT), lds, stream, a);
-        else hipLaunchKernelGGL((im2col_bf16_tile_kernel<T, MOD, 8, false>), grid, dim3(IT), lds, stream, a);
+        if (ncell <= 4) DDCN_I16_LAUNCH(4, false);
+        else if (ncell <= 6) DDCN_I16_LAUNCH(6, false);
+        else DDCN_I16_LAUNCH(8, false);
     }
+#undef DDCN_I16_LAUNCH
 }
 
 // 256 x 256 tiles.  DDCN_BF16_GEMM_PP=1 / 2 selects the phase-split (ping-pong) schedule, without / with a raised priority
