@@ -240,7 +240,7 @@ constexpr int TH = 8, TW = 32;
 // PIXOCT: pixel-octet columns (the B operand of G3) instead of k-octets; a template parameter because the two store paths
 // in one body cost 60 VGPRs (and with them the room for the second staging register set)
 template <typename T, bool MOD, int NCELL, bool PAIR, bool PIXOCT = false>
-__global__ __launch_bounds__(IT, 2) void im2col_bf16_tile_kernel(const Bf16Args a)
+__global__ __launch_bounds__(IT, (PAIR && !PIXOCT) ? 3 : 2) void im2col_bf16_tile_kernel(const Bf16Args a)
 {
     extern __shared__ u32x4 patch[];
     const int t = threadIdx.x;
