@@ -389,14 +389,17 @@ def inference_workload(args, world, rank, dev):
 def allreduce_probe(dev, world, nbytes, iters=10):
     """One fp32 all-reduce (SUM) of `nbytes` over the job's ranks, alone: ms per call (max over ranks is implied by
     the collective) and bus bandwidth 2(N-1)/N * bytes / time, the figure comparable to the 7 x ~153 GB/s xGMI links."""
+    drain = importlib.import_module("semantic-segmentation_amd.dist_utils").drain_for_host_backend   # no-op under RCCL
     buf = torch.ones(nbytes // 4, device=dev)
     for _ in range(2):
+        drain(buf)
         dist.all_reduce(buf)
     torch.cuda.synchronize()
     dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(iters):
+        drain(buf)
         dist.all_reduce(buf)
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / iters
@@ -548,7 +551,8 @@ def main():
         # (DDCN-ResNet101 + DANet head: ~69 M fp32 parameters = 276 MB in one step)
         line["allreduce"] = {"grad_weight": allreduce_probe(dev, world, weight.numel() * 4),
                              "configs3_gradient": allreduce_probe(dev, world, 69_000_000 * 4, iters=5),
-                             "backend": "nccl (RCCL)", "distinct_devices": len({tuple(d[1:]) for d in devices})}
+                             "backend": "nccl (RCCL)" if args.backend == "nccl" else "gloo (rehearsal)",
+                             "distinct_devices": len({tuple(d[1:]) for d in devices})}
     if rank == 0 and world == 1 and not args.no_kernel_timing:
         ks, traffic_src = kernel_rooflines(w, [t.detach() for t in (x, weight, offset, mask)] + [gout],
                                            max(5, args.steps // 2))

@@ -8,6 +8,7 @@ after backward by `dist_utils.allreduce_grads` (RCCL over xGMI under backend "nc
 import torch
 import torch.distributed as dist
 
+from .. import dist_utils
 from ..dist_utils import allreduce_grads
 
 # configs/*/danet_*_depthdeform.py: backbone x1, head x10, depth backbone x10
@@ -99,6 +100,7 @@ class OverlappedGradReducer:
     def _launch_next(self):
         bucket = self.buckets[self._next]
         flat = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1) for p in bucket])
+        dist_utils.drain_for_host_backend(flat, self.group)
         self._inflight.append((flat, dist.all_reduce(flat, group=self.group, async_op=True)))
         self.issued_order.append(self._next)
         self._next += 1

@@ -33,9 +33,18 @@ def _split_into_buckets(tensors, bucket_size_mb):
             yield bucket
 
 
+def drain_for_host_backend(tensor, group=None):
+    """gloo moves a GPU tensor through host memory from a worker thread.  With the producing kernels still queued on the
+    stream, two ranks that share ONE GPU (the CPU-backend rehearsal of the N-rank path) wait for each other forever
+    (tools/gloo_probe.py); draining the stream first avoids it.  A no-op for RCCL ("nccl"), which is stream-ordered."""
+    if tensor.is_cuda and dist.get_backend(group) == "gloo":
+        torch.cuda.current_stream(tensor.device).synchronize()
+
+
 def _allreduce_coalesced(tensors, world_size, bucket_size_mb=-1):
     for bucket in _split_into_buckets(tensors, bucket_size_mb):
         flat = torch.cat([t.reshape(-1) for t in bucket])
+        drain_for_host_backend(flat)
         dist.all_reduce(flat)          # SUM ...
         flat.div_(world_size)          # ... then the mean, as the reference does
         start = 0
@@ -53,7 +62,9 @@ def allreduce_grads(model_or_params, coalesce=True, bucket_size_mb=32):
         _allreduce_coalesced(grads, world_size, bucket_size_mb)
         return
     for g in grads:
-        dist.all_reduce(g.div_(world_size))
+        g.div_(world_size)
+        drain_for_host_backend(g)
+        dist.all_reduce(g)
 
 
 def shard_batch(n_images, rank, world_size):

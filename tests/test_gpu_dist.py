@@ -50,6 +50,28 @@ def test_bench_gpus2_syncbn_model_workload_on_rccl():
     assert line["final_loss"] == line["final_loss"] and line["final_loss"] > 0      # finite
 
 
+def test_bench_gpus2_rehearsal_on_one_gpu_over_gloo():
+    """The N-rank path end to end on the one GPU this box has: bench.py starts its two ranks itself, both run the layer
+    on the same device, the gradient goes through gloo (dist_utils drains the stream first: two ranks sharing a GPU
+    otherwise wait for each other inside gloo), rank 0 prints the one line."""
+    line = _bench("--gpus", "2", "--backend", "gloo", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", timeout=100)
+    assert line["n_gpus"] == 2 and line["config"]["parallelism"] == "dp2" and len(line["devices"]) == 2
+    assert line["allreduce"]["backend"].startswith("gloo") and line["allreduce"]["distinct_devices"] == 1
+    assert line["allreduce"]["grad_weight"]["bytes"] == 512 * 512 * 9 * 4 and line["value"] > 0
+
+
+def test_bench_gpus2_model_workload_rehearsal_over_gloo():
+    """configs[3]'s training step with two ranks on the one GPU: bucketed gradient all-reduce issued from inside backward
+    (OverlappedGradReducer, async collectives) over gloo, reduced input size.  (SyncBatchNorm's own collectives cannot be
+    drained from here, so the SyncBN variant needs RCCL and two GPUs: the test above.)"""
+    line = _bench("--gpus", "2", "--backend", "gloo", "--workload", "r50", "--batch", "1", "--hw", "97", "129",
+                  "--steps", "2", "--warmup", "1", timeout=110)
+    assert line["n_gpus"] == 2 and line["config"]["parallelism"] == "dp2" and line["config"]["norm"] == "BN"
+    assert line["config"]["allreduce"].startswith("32 MiB buckets")
+    assert line["allreduce"]["backend"].startswith("gloo") and line["allreduce"]["gradient"]["bytes"] > 100e6
+    assert line["final_loss"] == line["final_loss"] and line["final_loss"] > 0
+
+
 def test_bench_single_gpu_line_has_the_contract_fields():
     line = _bench("--steps", "3", "--warmup", "1", "--no-cpu-baseline")
     assert line["n_gpus"] == 1 and line["metric"] == "DDCN op fwd+bwd GB/s" and line["dtype"] == "f32"
