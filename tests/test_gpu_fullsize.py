@@ -144,3 +144,26 @@ def test_full_size_bf16_layers_against_exact_bf16_columns(name, C, H, W, dil):
     tight = tb._exact_bf16_columns_result(c, x, off, mask, w, bias, Ho, Wo)
     bound = 2.0 ** -8 * np.abs(tight) + 1e-3 * np.abs(tight).max()
     assert np.all(np.abs(got - tight) <= bound), float((np.abs(got - tight) / bound).max())
+
+
+# ---------------------------------------------------------------- 16-bit training at the bench layer's size
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16], ids=["bf16", "f16"])
+def test_full_size_16bit_training_step_native_against_fp32_kernels(dtype, monkeypatch):
+    """The bench layer (N=2, C=512, 97x97, dil 4) on 16-bit tensors: the native step (16-bit forward, G2 and G3 on the
+    16-bit operands with 256x256 tiles and split-K, G3's chain on the side stream) against the same tensors through the
+    fp32 kernels (convert in / out).  Both round their results to 16 bits; the native one also rounds the columns."""
+    dcn = importlib.import_module("semantic-segmentation_amd.dcn.deform_conv")
+    x, w, off, mask, gout = _raw_inputs(2, 512, 512, 97, 97, 4, 1, 2.0, seed=77)
+    tol = 1.5e-2 if dtype == torch.bfloat16 else 3e-3
+
+    def run(native):
+        monkeypatch.setattr(dcn, "TRAIN16_NATIVE", native)
+        t = [v.to(DEV).to(dtype).requires_grad_(True) for v in (x, off, mask, w)]
+        out = pkg.modulated_deform_conv(t[0], t[1], t[2], t[3], None, 1, 4, 4, 1, 1)
+        out.backward(gout.to(DEV).to(dtype))
+        torch.cuda.synchronize()
+        return [out.detach()] + [v.grad for v in t]
+    a, b = run(True), run(False)
+    for name, u, v in zip(("out", "gx", "goff", "gmask", "gw"), a, b):
+        assert u.dtype == dtype and torch.isfinite(u.float()).all(), name
+        assert cases.relerr(u.double().cpu().numpy(), v.double().cpu().numpy()) <= tol, name
