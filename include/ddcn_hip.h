@@ -130,6 +130,14 @@ int ddcn_deform_conv_direct_forward_f32(const float *x, const float *weight, con
 int ddcn_deform_conv_direct_backward_f32(const float *x, const float *weight, const float *offset,
                                          const float *grad_out, float *gx, float *goff, float *gw, float *gb,
                                          void *workspace, size_t workspace_bytes, const ddcn_geom *g, void *stream);
+
+/* The same backward with the weight gradient (and bias gradient) on a second stream of the caller, beside the scatter:
+ * the caller passes the side stream and two events (recorded at least once), the library creates nothing and joins the
+ * side stream back into `stream` before returning.  No counterpart in the reference (one stream, H:253-367). */
+int ddcn_deform_conv_direct_backward_2s_f32(const float *x, const float *weight, const float *offset,
+                                            const float *grad_out, float *gx, float *goff, float *gw, float *gb,
+                                            void *workspace, size_t workspace_bytes, const ddcn_geom *g, void *stream,
+                                            void *side_stream, void *fork_event, void *join_event);
 /* replaces deform_conv_cuda_backward (H:253-367) */
 int ddcn_deform_conv_backward_f32(const float *x, const float *weight, const float *offset, const float *grad_out,
                                   float *gx, float *goff, float *gw, float *gb, void *workspace,

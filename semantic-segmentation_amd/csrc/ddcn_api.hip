@@ -307,6 +307,49 @@ int ddcn_deform_conv_direct_backward_f32(const float *x, const float *weight, co
     return DDCN_OK;
 }
 
+// The same backward with the weight gradient on a second stream of the caller, beside the scatter: the two direct
+// kernels are independent (grad_input / grad_offset from the LDS-atomic-bound scatter, grad_weight from the VALU-bound
+// per-channel sampling kernel) and share nothing but read-only inputs; the workspace is split between them (repacked
+// weights first, the sample table behind).  Geometries one of them does not cover run that half on `stream`, in order.
+int ddcn_deform_conv_direct_backward_2s_f32(const float *x, const float *weight, const float *offset,
+                                            const float *grad_out, float *gx, float *goff, float *gw, float *gb,
+                                            void *workspace, size_t workspace_bytes, const ddcn_geom *g, void *stream,
+                                            void *side_stream, void *fork_event, void *join_event)
+{
+    REQUIRE(x); REQUIRE(weight); REQUIRE(offset); REQUIRE(grad_out); REQUIRE(gx); REQUIRE(goff); REQUIRE(gw);
+    REQUIRE(side_stream); REQUIRE(fork_event); REQUIRE(join_event);
+    if (side_stream == stream) return fail(DDCN_ERR_BAD_ARG, "side_stream must differ from stream");
+    TRY(check_geom(g));
+    TRY(check_ws(g, workspace, workspace_bytes));
+    hipStream_t s = (hipStream_t)stream, s2 = (hipStream_t)side_stream;
+    hipEvent_t fork = (hipEvent_t)fork_event, join = (hipEvent_t)join_event;
+    float *col = (float *)workspace;
+    const size_t lo = round_up((size_t)g->C * 9 * 12 * sizeof(float), 256);     // launch_skinny_scatter's repacked weights
+    if (workspace_bytes <= lo)       // tiny maps: nothing to split, nothing to gain
+        return ddcn_deform_conv_direct_backward_f32(x, weight, offset, grad_out, gx, goff, gw, gb, workspace, workspace_bytes, g, stream);
+    hipError_t e = hipEventRecord(fork, s);
+    if (e == hipSuccess) e = hipStreamWaitEvent(s2, fork, 0);
+    if (e != hipSuccess) return fail(DDCN_ERR_LAUNCH, "two-stream direct backward: fork: %s", hipGetErrorString(e));
+    bool hw = false, hs = false;
+    TRY(launch_skinny_gweight(x, offset, grad_out, gw, (char *)workspace + lo, workspace_bytes - lo, *g, s2, &hw));
+    if (gb) TRY(launch_bias_grad(grad_out, gb, *g, s2));
+    e = hipEventRecord(join, s2);
+    if (e != hipSuccess) return fail(DDCN_ERR_LAUNCH, "two-stream direct backward: join: %s", hipGetErrorString(e));
+    TRY(launch_skinny_scatter(x, offset, weight, grad_out, gx, goff, workspace, lo, *g, s, &hs));
+    // everything below runs on `stream` after the side stream's work (the fallbacks use the whole workspace)
+    e = hipStreamWaitEvent(s, join, 0);
+    if (e != hipSuccess) return fail(DDCN_ERR_LAUNCH, "two-stream direct backward: join: %s", hipGetErrorString(e));
+    if (!hs) {
+        TRY(launch_gemm_gcol(weight, grad_out, col, *g, s));
+        TRY(launch_col2im_coord(col, x, offset, nullptr, gx, goff, nullptr, *g, s, /*clear_coord=*/false));
+    }
+    if (!hw) {
+        TRY(launch_im2col(x, offset, nullptr, col, *g, s));
+        TRY(launch_gemm_gweight(grad_out, col, gw, *g, s));
+    }
+    return DDCN_OK;
+}
+
 int ddcn_deform_conv_backward_f32(const float *x, const float *weight, const float *offset, const float *grad_out,
                                   float *gx, float *goff, float *gw, float *gb, void *workspace,
                                   size_t workspace_bytes, const ddcn_geom *g, void *stream)

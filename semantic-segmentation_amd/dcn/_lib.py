@@ -54,6 +54,7 @@ PROTOTYPES = {
     "ddcn_deform_conv_direct_forward_f32": [_P, _P, _P, _P, _P, ctypes.c_int, _P, _SZ, _G, _P],
     "ddcn_deform_conv_backward_f32": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _SZ, _G, _P],
     "ddcn_deform_conv_direct_backward_f32": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _SZ, _G, _P],
+    "ddcn_deform_conv_direct_backward_2s_f32": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _SZ, _G, _P, _P, _P, _P],
     "ddcn_modulated_deform_conv_forward_f32": [_P, _P, _P, _P, _P, _P, _P, _SZ, _G, _P],
     "ddcn_static_scratch_bytes": [],
     "ddcn_modulated_deform_conv_forward_static_f32": [_P, _P, _P, _P, _P, _P, _G, _P],

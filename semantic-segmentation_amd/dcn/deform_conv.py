@@ -563,10 +563,17 @@ class _DeformConvSigmoidFunction(Function):
         _expect_shape("grad_output", grad_pre, (g.N, g.Co, g.Ho, g.Wo))
         ws, ws_bytes = _workspace(input, g, cd)
         with torch.cuda.device(input.device):
-            _lib.check(_entry("ddcn_deform_conv_direct_backward", cd)(
-                _lib.ptr(input), _lib.ptr(weight), _lib.ptr(offset), _lib.ptr(grad_pre), _lib.ptr(grad_input),
-                _lib.ptr(grad_offset), _lib.ptr(grad_weight), _lib.ptr(grad_bias) if ctx.with_bias else None,
-                _lib.ptr(ws), ws_bytes, g, _lib.current_stream(input.device)))
+            args = (_lib.ptr(input), _lib.ptr(weight), _lib.ptr(offset), _lib.ptr(grad_pre), _lib.ptr(grad_input),
+                    _lib.ptr(grad_offset), _lib.ptr(grad_weight), _lib.ptr(grad_bias) if ctx.with_bias else None,
+                    _lib.ptr(ws), ws_bytes, g, _lib.current_stream(input.device))
+            if TWO_STREAM_BACKWARD and cd == torch.float32 and not torch.cuda.is_current_stream_capturing():
+                # the weight-gradient kernel on the side stream beside the scatter (independent halves of the backward)
+                side, fork, join = _side_stream(input.device)
+                _lib.check(_lib.lib().ddcn_deform_conv_direct_backward_2s_f32(
+                    *args, ctypes.c_void_p(side.cuda_stream), ctypes.c_void_p(fork.cuda_event),
+                    ctypes.c_void_p(join.cuda_event)))
+            else:
+                _lib.check(_entry("ddcn_deform_conv_direct_backward", cd)(*args))
         if not ctx.with_bias:
             grad_bias = None
         if ctx.dtype != cd:

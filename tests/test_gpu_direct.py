@@ -70,12 +70,24 @@ def test_direct_forward_and_backward_match_oracle(c):
     assert cases.relerr(gw.cpu().numpy(), egw) <= BWD_TOL, cases.relerr(gw.cpu().numpy(), egw)
     if c["bias"]:
         assert cases.relerr(gb.cpu().numpy(), egb) <= BWD_TOL
-    # backward ACCUMULATES: a second call doubles every gradient
-    _lib.check(L.ddcn_deform_conv_direct_backward_f32(_lib.ptr(x), _lib.ptr(w), _lib.ptr(off), _lib.ptr(gout),
-                                                      _lib.ptr(gx), _lib.ptr(goff), _lib.ptr(gw), _lib.ptr(gb),
-                                                      _lib.ptr(ws), nbytes, g, s))
-    torch.cuda.synchronize()
+    # backward ACCUMULATES: a second call doubles every gradient -- made through the two-stream entry point (weight
+    # gradient on a side stream beside the scatter; geometries a direct kernel does not cover take its in-order fallback)
+    import ctypes
+    main, side = torch.cuda.current_stream(), torch.cuda.Stream()
+    fork, join = torch.cuda.Event(), torch.cuda.Event()
+    fork.record(side); join.record(side)
+    _lib.check(L.ddcn_deform_conv_direct_backward_2s_f32(
+        _lib.ptr(x), _lib.ptr(w), _lib.ptr(off), _lib.ptr(gout), _lib.ptr(gx), _lib.ptr(goff), _lib.ptr(gw), _lib.ptr(gb),
+        _lib.ptr(ws), nbytes, g, s, ctypes.c_void_p(side.cuda_stream), ctypes.c_void_p(fork.cuda_event),
+        ctypes.c_void_p(join.cuda_event)))
+    main.synchronize()           # the call joined the side stream into the caller's: this alone covers the weight gradient
     assert cases.relerr(gw.cpu().numpy(), 2 * egw) <= BWD_TOL and cases.relerr(gx.cpu().numpy(), 2 * egx) <= BWD_TOL
+    assert cases.relerr(goff.cpu().numpy(), 2 * egoff) <= BWD_TOL
+    if c["bias"]:
+        assert cases.relerr(gb.cpu().numpy(), 2 * egb) <= BWD_TOL
+    assert L.ddcn_deform_conv_direct_backward_2s_f32(
+        _lib.ptr(x), _lib.ptr(w), _lib.ptr(off), _lib.ptr(gout), _lib.ptr(gx), _lib.ptr(goff), _lib.ptr(gw), _lib.ptr(gb),
+        _lib.ptr(ws), nbytes, g, s, s, ctypes.c_void_p(fork.cuda_event), ctypes.c_void_p(join.cuda_event)) == -1
 
 
 def test_direct_backward_full_size_mask_branch_against_oracle():
