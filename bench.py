@@ -275,8 +275,9 @@ def model_workload(args, world, rank, dev):
                  HHA=torch.randn(n, 3, cfg["h"], cfg["w"], generator=g).to(dev), gt_label=label.to(dev))
     total = args.warmup + args.steps
     it = 0
+    amp = torch.bfloat16 if args.amp == "bf16" else None
     for _ in range(args.warmup):
-        callers.train_step(model, opt, batch, it, total, reducer=reducer)
+        callers.train_step(model, opt, batch, it, total, reducer=reducer, amp_dtype=amp)
         it += 1
     torch.cuda.synchronize()
     if world > 1:
@@ -284,7 +285,7 @@ def model_workload(args, world, rank, dev):
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        loss = callers.train_step(model, opt, batch, it, total, reducer=reducer)
+        loss = callers.train_step(model, opt, batch, it, total, reducer=reducer, amp_dtype=amp)
         it += 1
     torch.cuda.synchronize()
     if world > 1:
@@ -303,7 +304,8 @@ def model_workload(args, world, rank, dev):
             "metric": "train images/sec", "value": round(n * world * args.steps / dt, 3), "unit": "images/s",
             "n_gpus": dist.get_world_size() if world > 1 else 1, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "vs_baseline": None, "dtype": "f32" if amp is None else "bf16 activations under autocast, fp32 parameters",
+            "data": "synthetic",
             "config": {"workload": cfg["name"] + ", %d images/GPU, fwd+bwd+SGD step, random init" % n,
                        "images_per_gpu": n, "parallelism": "dp%d" % world,
                        "params_M": round(sum(p.numel() for p in model.parameters()) / 1e6, 2),
@@ -446,6 +448,10 @@ def main():
                          "collectives go through host memory) -- its numbers are not a scaling measurement")
     ap.add_argument("--hw", type=int, nargs=2, metavar=("H", "W"), default=None,
                     help="model workloads: override the input size (rehearsals and tests; the reported workload says so)")
+    ap.add_argument("--amp", choices=("off", "bf16"), default="off",
+                    help="model workloads: forward and loss under torch.autocast(bfloat16) -- fp32 parameters, 16-bit "
+                         "activations, the DDCN layers on their native 16-bit forward / backward.  An extra figure: the "
+                         "reference trains in fp32 and the BASELINE workloads are quoted in fp32 (the default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     args = ap.parse_args()

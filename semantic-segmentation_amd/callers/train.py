@@ -35,14 +35,18 @@ def poly_lr(optimizer, it, max_iters, power=0.9, min_lr=0.0):
         group["lr"] = (group["initial_lr"] - min_lr) * coeff + min_lr
 
 
-def train_step(model, optimizer, batch, it=0, max_iters=1, ignore_index=255, bucket_size_mb=32, reducer=None):
+def train_step(model, optimizer, batch, it=0, max_iters=1, ignore_index=255, bucket_size_mb=32, reducer=None,
+               amp_dtype=None):
     """One iteration: poly lr, forward, loss, backward, gradient all-reduce when distributed, SGD update.
     `batch` = dict(img, HHA, gt_label) already on the device.  With `reducer` (an OverlappedGradReducer built on
-    the model) the all-reduce runs under backward; otherwise after it, as in the reference.  Returns the loss."""
+    the model) the all-reduce runs under backward; otherwise after it, as in the reference.  Returns the loss.
+    `amp_dtype` (torch.bfloat16): forward and loss under torch.autocast -- fp32 parameters and optimizer, 16-bit
+    activations; the DDCN layers then run their native 16-bit forward and backward.  Not in the reference (fp32 only)."""
     poly_lr(optimizer, it, max_iters)
     optimizer.zero_grad(set_to_none=True)
-    losses = model(batch["img"], batch["gt_label"], batch.get("HHA"), ignore_index)
-    loss = sum(v for k, v in losses.items() if "loss" in k)
+    with torch.autocast("cuda", dtype=amp_dtype, enabled=amp_dtype is not None):
+        losses = model(batch["img"], batch["gt_label"], batch.get("HHA"), ignore_index)
+        loss = sum(v.float() for k, v in losses.items() if "loss" in k)
     loss.backward()
     if reducer is not None:
         reducer.finish()

@@ -97,6 +97,9 @@ BF16_NATIVE = os.environ.get("DDCN_BF16_NATIVE", "1") != "0"
 # Saved-columns fp32 backward on two streams (ddcn_deform_conv_backward_saved_2s_f32): the weight-gradient GEMM runs on
 # a side stream beside the LDS-atomic-bound scatter.  DDCN_TWO_STREAM_BACKWARD=0 keeps everything on one stream.
 TWO_STREAM_BACKWARD = os.environ.get("DDCN_TWO_STREAM_BACKWARD", "1") != "0"
+# the mask branch's direct backward on two streams (ddcn_deform_conv_direct_backward_2s_f32): measured -0.03 ms on the
+# 3.46 ms layer, so it is opt-in
+TWO_STREAM_DIRECT = os.environ.get("DDCN_TWO_STREAM_DIRECT", "0") == "1"
 _side = {}
 
 
@@ -566,7 +569,8 @@ class _DeformConvSigmoidFunction(Function):
             args = (_lib.ptr(input), _lib.ptr(weight), _lib.ptr(offset), _lib.ptr(grad_pre), _lib.ptr(grad_input),
                     _lib.ptr(grad_offset), _lib.ptr(grad_weight), _lib.ptr(grad_bias) if ctx.with_bias else None,
                     _lib.ptr(ws), ws_bytes, g, _lib.current_stream(input.device))
-            if TWO_STREAM_BACKWARD and cd == torch.float32 and not torch.cuda.is_current_stream_capturing():
+            if (TWO_STREAM_DIRECT and TWO_STREAM_BACKWARD and cd == torch.float32
+                    and not torch.cuda.is_current_stream_capturing()):
                 # the weight-gradient kernel on the side stream beside the scatter (independent halves of the backward)
                 side, fork, join = _side_stream(input.device)
                 _lib.check(_lib.lib().ddcn_deform_conv_direct_backward_2s_f32(
@@ -582,6 +586,18 @@ class _DeformConvSigmoidFunction(Function):
         return (grad_input, grad_offset, grad_weight, grad_bias, None, None, None, None, None)
 
 
+def _autocast_view(tensors):
+    """Under torch.autocast("cuda", dtype) a custom Function gets its inputs as they come: 16-bit activations from the
+    autocast convolutions before it, fp32 parameters.  The reference's Functions predate autocast and would fail on the
+    mixed dtypes; here the functional aliases cast every floating CUDA tensor of the call to the autocast dtype (a
+    differentiable cast: parameter gradients come back in fp32), so that the native 16-bit kernels run."""
+    if not torch.is_autocast_enabled("cuda"):
+        return tensors
+    dt = torch.get_autocast_dtype("cuda")
+    return tuple(t.to(dt) if isinstance(t, torch.Tensor) and t.is_cuda and t.is_floating_point() and t.dtype != dt else t
+                 for t in tensors)
+
+
 def _inference_view(tensors):
     """Inside Function.forward a Parameter looks the same with and without torch.no_grad() (requires_grad stays
     True), so the reference saves its tensors for a backward that can never come.  The functional aliases below hand
@@ -594,7 +610,7 @@ def _inference_view(tensors):
 
 def deform_conv(input, offset, weight, bias=None, stride=1, padding=0, dilation=1, groups=1, deformable_groups=1):
     """`DeformConvFunction.apply` (PY:226) with the reference's positional argument order."""
-    input, offset, weight, bias = _inference_view((input, offset, weight, bias))
+    input, offset, weight, bias = _inference_view(_autocast_view((input, offset, weight, bias)))
     return DeformConvFunction.apply(input, offset, weight, bias, stride, padding, dilation, groups,
                                     deformable_groups)
 
@@ -602,14 +618,14 @@ def deform_conv(input, offset, weight, bias=None, stride=1, padding=0, dilation=
 def modulated_deform_conv(input, offset, mask, weight, bias=None, stride=1, padding=0, dilation=1, groups=1,
                           deformable_groups=1):
     """`ModulatedDeformConvFunction.apply` (PY:227) with the reference's positional argument order."""
-    input, offset, mask, weight, bias = _inference_view((input, offset, mask, weight, bias))
+    input, offset, mask, weight, bias = _inference_view(_autocast_view((input, offset, mask, weight, bias)))
     return ModulatedDeformConvFunction.apply(input, offset, mask, weight, bias, stride, padding, dilation, groups,
                                              deformable_groups)
 
 
 def depthaware_conv(input, depth, weight, bias=None, stride=1, padding=0, dilation=1, groups=1):
     """`DepthawareConvFunction.apply` (PY:228) with the reference's positional argument order."""
-    input, depth, weight, bias = _inference_view((input, depth, weight, bias))
+    input, depth, weight, bias = _inference_view(_autocast_view((input, depth, weight, bias)))
     return DepthawareConvFunction.apply(input, depth, weight, bias, stride, padding, dilation, groups)
 
 
@@ -762,7 +778,7 @@ class DepthDeformConvPack(ModulatedDeformConv):
         k2x2 = 2 * self.kernel_size[0] * self.kernel_size[1]
         mask_offset = offset if self.deformable_groups == 1 else offset[:, :k2x2].contiguous()
         cm = self.conv_mask
-        depth_v, mask_offset, cm_weight, cm_bias = _inference_view((depth, mask_offset, cm.weight, cm.bias))
+        depth_v, mask_offset, cm_weight, cm_bias = _inference_view(_autocast_view((depth, mask_offset, cm.weight, cm.bias)))
         mask = _DeformConvSigmoidFunction.apply(depth_v, mask_offset, cm_weight, cm_bias, cm.stride, cm.padding,
                                                 cm.dilation, cm.groups, cm.deformable_groups)
         self.offset, self.mask = offset, mask

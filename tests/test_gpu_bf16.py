@@ -323,3 +323,27 @@ def test_ddcn_layer_trains_on_16bit_tensors(fmt):
         assert cases.relerr(a[k].double().cpu().numpy(), b[k].double().cpu().numpy()) <= 2 * e2e_tol, k
     diff = (a["goff"].float() - b["goff"]).abs()
     assert float((diff > 0.05 * b["goff"].abs().max()).float().mean()) < 0.01
+
+
+def test_functional_aliases_follow_autocast():
+    """torch.autocast("cuda", bfloat16): fp32 parameters and fp32 / 16-bit activations reach the aliases mixed; they
+    cast the call to the autocast dtype (the reference's Functions predate autocast and reject mixed dtypes), the
+    native 16-bit kernels run, and the gradients of the fp32 leaves come back in fp32."""
+    c = BF16_CASES[1]
+    x, off, mask, w, bias, Ho, Wo = _inputs(c, seed=5)
+    f32 = lambda a: torch.from_numpy(np.asarray(a, dtype=np.float32)).to(DEV)
+    xt, wt = f32(x).requires_grad_(True), f32(w).requires_grad_(True)
+    offt, maskt = f32(off).bfloat16(), f32(mask).bfloat16()          # as an autocast convolution would hand them over
+    args = (c["stride"], c["pad"], c["dil"], c["groups"], c["dg"])
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        out = pkg.modulated_deform_conv(xt, offt, maskt, wt, None, *args)
+    assert out.dtype == torch.bfloat16
+    with torch.no_grad():
+        direct = pkg.modulated_deform_conv(xt.detach().bfloat16(), offt, maskt, wt.detach().bfloat16(), None, *args)
+    assert torch.equal(out.detach(), direct)                         # the same native 16-bit forward
+    out.float().sum().backward()
+    assert xt.grad.dtype == torch.float32 and wt.grad.dtype == torch.float32
+    assert torch.isfinite(xt.grad).all() and torch.isfinite(wt.grad).all() and float(wt.grad.abs().max()) > 0
+    # outside autocast mixed dtypes are still refused
+    with pytest.raises(RuntimeError):
+        pkg.modulated_deform_conv(xt, offt, maskt, wt, None, *args)
