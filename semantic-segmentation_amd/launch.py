@@ -13,9 +13,11 @@ parent's.  A process that already runs under torchrun (WORLD_SIZE set) never spa
 over xGMI; the CPU tests use gloo.
 """
 import os
+import signal
 import socket
 import subprocess
 import sys
+import threading
 import time
 
 SPAWNED_FLAG = "DDCN_SPAWNED_RANK"
@@ -53,6 +55,10 @@ def spawn_ranks(world_size, argv, script=None, poll_s=0.2):
     procs = [subprocess.Popen([sys.executable, "-u", script] + list(argv), env=rank_env(r, world_size, port))
              for r in range(world_size)]
     code = 0
+
+    def _on_term(signum, frame):      # a `timeout` / job scheduler ends the parent: take the ranks down with it
+        raise SystemExit(128 + signum)
+    previous = signal.signal(signal.SIGTERM, _on_term) if threading.current_thread() is threading.main_thread() else None
     try:
         live = set(range(world_size))
         while live and code == 0:
@@ -78,6 +84,8 @@ def spawn_ranks(world_size, argv, script=None, poll_s=0.2):
             except subprocess.TimeoutExpired:
                 p.kill()
                 p.wait()
+        if previous is not None:
+            signal.signal(signal.SIGTERM, previous)
     return code
 
 

@@ -2,12 +2,14 @@
 
   * RCCL, world size 2: needs two GPUs (skipped on the 1-GPU box; the driver's multi-GPU tier runs it).
   * the SyncBN variant of BASELINE configs[3] (configs/sunrgbd/danet_r101_depthdeform.py:13,20,26:
-    norm_cfg = SyncBN) likewise needs two GPUs: torch's SyncBatchNorm refuses CPU tensors, and two ranks sharing ONE
-    GPU over gloo (`bench.py --backend gloo`) stall inside SyncBatchNorm's all_gather after a few layers on this
-    stack (measured in round 2; plain gloo collectives on GPU tensors work), so no one-GPU rehearsal is collected.
+    norm_cfg = SyncBN) likewise needs two GPUs: torch's SyncBatchNorm refuses CPU tensors and its own collectives cannot
+    be drained for gloo from outside.
+  * gloo, world size 2, both ranks on the ONE GPU: the rehearsal of the whole path (spawn, env contract, the gradient
+    exchange after / from inside backward) for the layer and the plain-BN model workload.
 """
 import json
 import os
+import signal
 import subprocess
 import sys
 
@@ -21,11 +23,19 @@ pytestmark = pytest.mark.gpu
 
 def _bench(*argv, timeout=600):
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + list(argv), env=env, capture_output=True,
-                       text=True, timeout=timeout)
-    assert r.returncode == 0, r.stderr[-2000:]
-    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
-    assert len(lines) == 1, r.stdout          # ONE JSON line, from rank 0
+    # its own process group: if the job hangs, the ranks it spawned go down with it (killing only the parent would
+    # leave them on the GPU)
+    proc = subprocess.Popen([sys.executable, os.path.join(ROOT, "bench.py")] + list(argv), env=env, stdout=subprocess.PIPE,
+                            stderr=subprocess.PIPE, text=True, start_new_session=True)
+    try:
+        stdout, stderr = proc.communicate(timeout=timeout)
+    except subprocess.TimeoutExpired:
+        os.killpg(proc.pid, signal.SIGKILL)       # the group this call started, by its own id
+        proc.communicate()
+        raise
+    assert proc.returncode == 0, stderr[-2000:]
+    lines = [l for l in stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, stdout            # ONE JSON line, from rank 0
     return json.loads(lines[0])
 
 

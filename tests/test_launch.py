@@ -92,3 +92,34 @@ def test_bench_gpus_flag_is_not_decorative():
         assert r.returncode != 0 and "--gpus 2: only" in r.stderr
     src = open(os.path.join(ROOT, "bench.py")).read()
     assert "spawn_ranks(args.gpus" in src and "dist.get_world_size()" in src
+
+
+def test_spawn_ranks_takes_its_ranks_down_when_terminated(tmp_path):
+    """SIGTERM to the parent (a `timeout`, a scheduler): the ranks it started must not stay behind."""
+    import signal
+    import time
+    script = tmp_path / "sleeper.py"
+    script.write_text(
+        "import os, sys, time\n"
+        "sys.path.insert(0, %r)\n"
+        "import importlib\n"
+        "launch = importlib.import_module('semantic-segmentation_amd.launch')\n"
+        "if not launch.under_launcher():\n"
+        "    sys.exit(launch.spawn_ranks(2, [sys.argv[1]], script=__file__))\n"
+        "open(os.path.join(sys.argv[1], 'pid%%s' %% os.environ['RANK']), 'w').write(str(os.getpid()))\n"
+        "time.sleep(60)\n" % ROOT)
+    p = subprocess.Popen([sys.executable, str(script), str(tmp_path)])
+    deadline = time.time() + 30
+    while time.time() < deadline and not all((tmp_path / ("pid%d" % r)).exists() for r in range(2)):
+        time.sleep(0.1)
+    pids = [int((tmp_path / ("pid%d" % r)).read_text()) for r in range(2)]
+    p.send_signal(signal.SIGTERM)
+    assert p.wait(timeout=30) != 0
+    time.sleep(0.5)
+    for pid in pids:
+        try:
+            os.kill(pid, 0)
+            alive = True
+        except ProcessLookupError:
+            alive = False
+        assert not alive, "rank %d survived its launcher" % pid
