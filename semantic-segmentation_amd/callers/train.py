@@ -105,7 +105,12 @@ class OverlappedGradReducer:
         bucket = self.buckets[self._next]
         flat = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1) for p in bucket])
         dist_utils.drain_for_host_backend(flat, self.group)
-        self._inflight.append((flat, dist.all_reduce(flat, group=self.group, async_op=True)))
+        work = dist.all_reduce(flat, group=self.group, async_op=True)
+        if flat.is_cuda and dist.get_backend(self.group) == "gloo":
+            # the one-GPU rehearsal: no kernel of this process may be queued while gloo moves the bucket through the host
+            # (dist_utils.drain_for_host_backend), so backward does not run on under it -- nothing overlaps here
+            work.wait()
+        self._inflight.append((flat, work))
         self.issued_order.append(self._next)
         self._next += 1
 
