@@ -235,11 +235,15 @@ static int deform_backward(const float *x, const float *weight, const float *off
         hipError_t e = hipEventRecord(side->fork, s);
         if (e == hipSuccess) e = hipStreamWaitEvent(side->stream, side->fork, 0);
         if (e != hipSuccess) return fail(DDCN_ERR_LAUNCH, "two-stream backward: fork: %s", hipGetErrorString(e));
-        TRY(launch_gemm_gweight(gout, saved_cols, gw, *g, side->stream));
-        if (gb) TRY(launch_bias_grad(gout, gb, *g, side->stream));
-        TRY(launch_col2im_coord(col, x, offset, mask, gx, goff, gmask, *g, s, /*clear_coord=*/false, /*chunk_channels=*/2));
+        // from here on the side stream may hold work: whatever fails, the caller's stream still joins it before this
+        // call returns (the caller frees gw / gb / the workspace on ITS stream's order)
+        int rc = launch_gemm_gweight(gout, saved_cols, gw, *g, side->stream);
+        if (rc == DDCN_OK && gb) rc = launch_bias_grad(gout, gb, *g, side->stream);
+        if (rc == DDCN_OK)
+            rc = launch_col2im_coord(col, x, offset, mask, gx, goff, gmask, *g, s, /*clear_coord=*/false, /*chunk_channels=*/2);
         e = hipEventRecord(side->join, side->stream);
         if (e == hipSuccess) e = hipStreamWaitEvent(s, side->join, 0);
+        if (rc != DDCN_OK) return rc;
         if (e != hipSuccess) return fail(DDCN_ERR_LAUNCH, "two-stream backward: join: %s", hipGetErrorString(e));
         return DDCN_OK;
     }
@@ -324,20 +328,21 @@ int ddcn_deform_conv_direct_backward_2s_f32(const float *x, const float *weight,
     hipStream_t s = (hipStream_t)stream, s2 = (hipStream_t)side_stream;
     hipEvent_t fork = (hipEvent_t)fork_event, join = (hipEvent_t)join_event;
     float *col = (float *)workspace;
-    const size_t lo = round_up((size_t)g->C * 9 * 12 * sizeof(float), 256);     // launch_skinny_scatter's repacked weights
+    const size_t lo = skinny_scatter_ws_bytes(*g);     // launch_skinny_scatter's repacked weights
     if (workspace_bytes <= lo)       // tiny maps: nothing to split, nothing to gain
         return ddcn_deform_conv_direct_backward_f32(x, weight, offset, grad_out, gx, goff, gw, gb, workspace, workspace_bytes, g, stream);
     hipError_t e = hipEventRecord(fork, s);
     if (e == hipSuccess) e = hipStreamWaitEvent(s2, fork, 0);
     if (e != hipSuccess) return fail(DDCN_ERR_LAUNCH, "two-stream direct backward: fork: %s", hipGetErrorString(e));
+    // after the fork every exit joins the side stream first (its kernels write gw, gb and the workspace)
     bool hw = false, hs = false;
-    TRY(launch_skinny_gweight(x, offset, grad_out, gw, (char *)workspace + lo, workspace_bytes - lo, *g, s2, &hw));
-    if (gb) TRY(launch_bias_grad(grad_out, gb, *g, s2));
+    int rc = launch_skinny_gweight(x, offset, grad_out, gw, (char *)workspace + lo, workspace_bytes - lo, *g, s2, &hw);
+    if (rc == DDCN_OK && gb) rc = launch_bias_grad(grad_out, gb, *g, s2);
     e = hipEventRecord(join, s2);
-    if (e != hipSuccess) return fail(DDCN_ERR_LAUNCH, "two-stream direct backward: join: %s", hipGetErrorString(e));
-    TRY(launch_skinny_scatter(x, offset, weight, grad_out, gx, goff, workspace, lo, *g, s, &hs));
+    if (rc == DDCN_OK) rc = launch_skinny_scatter(x, offset, weight, grad_out, gx, goff, workspace, lo, *g, s, &hs);
     // everything below runs on `stream` after the side stream's work (the fallbacks use the whole workspace)
-    e = hipStreamWaitEvent(s, join, 0);
+    if (e == hipSuccess) e = hipStreamWaitEvent(s, join, 0);
+    if (rc != DDCN_OK) return rc;
     if (e != hipSuccess) return fail(DDCN_ERR_LAUNCH, "two-stream direct backward: join: %s", hipGetErrorString(e));
     if (!hs) {
         TRY(launch_gemm_gcol(weight, grad_out, col, *g, s));

@@ -69,6 +69,8 @@ int launch_col2im_coord_tile9(const float *gcol, const float *x, const float *of
                               int chunk_channels = 0, const float *sk_w = nullptr, const float *sk_g = nullptr);
 int launch_skinny_scatter(const float *x, const float *offset, const float *weight, const float *gout, float *gx,
                           float *goff, void *ws, size_t ws_bytes, const ddcn_geom &g, hipStream_t stream, bool *handled);
+// bytes launch_skinny_scatter takes from the front of its workspace (the repacked weights), 256-byte granular
+size_t skinny_scatter_ws_bytes(const ddcn_geom &g);
 int launch_col2im_coord_tiled(const float *gcol, const float *x, const float *offset, const float *mask, float *gx,
                               float *goff, float *gmask, const ddcn_geom &g, hipStream_t stream, bool *handled);
 int launch_depthaware_im2col(const float *x, const float *depth, float *col, const ddcn_geom &g,

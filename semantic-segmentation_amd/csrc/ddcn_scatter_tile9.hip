@@ -627,6 +627,11 @@ __global__ __launch_bounds__(256) void repack_skinny_w_kernel(const float *w, fl
     wp[i] = o < Co ? w[(long)o * C * 9 + ck] : 0.f;
 }
 
+size_t skinny_scatter_ws_bytes(const ddcn_geom &g)
+{
+    return round_up((size_t)g.C * 9 * SKB_MAX * sizeof(float), 256);
+}
+
 // Direct backward scatter for few output channels: grad_input / grad_offset straight from grad_out (no column
 // gradients in memory).  `ws` receives the repacked weights (C * 9 * 12 floats).  *handled = false: not covered.
 int launch_skinny_scatter(const float *x, const float *offset, const float *weight, const float *gout, float *gx,

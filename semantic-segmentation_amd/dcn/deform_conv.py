@@ -148,11 +148,18 @@ def _backward_saved(cd, input, weight, offset, mask, grad_output, cols, grad_inp
 TRAIN16_NATIVE = os.environ.get("DDCN_16BIT_TRAIN_NATIVE", "1") != "0"
 
 
+def _backward_16bit_covers(dtype, g):
+    """True when backward of a call on `dtype` tensors will take _backward_16bit (which recomputes its columns in 16 bits):
+    the forward then keeps no fp32 columns for it."""
+    return (dtype in (torch.bfloat16, torch.float16) and TRAIN16_NATIVE
+            and _lib.lib().ddcn_gemm_gcol_16_supported(g) == 0)
+
+
 def _backward_16bit(dtype, input, offset, mask, weight, grad_output, with_bias, g):
     """(grad_input, grad_offset, grad_mask | None, grad_weight, grad_bias | None) in `dtype`, or None when the 16-bit
     G2 does not cover the geometry.  All tensors are 16-bit; mask None = the non-modulated op."""
     L = _lib.lib()
-    if not TRAIN16_NATIVE or L.ddcn_gemm_gcol_16_supported(g) != 0:
+    if not _backward_16bit_covers(dtype, g):
         return None
     p = _lib.ptr
     grad_output = grad_output.contiguous()
@@ -311,7 +318,7 @@ class DeformConvFunction(Function):
             _lib.check(_entry("ddcn_deform_conv_forward", cd)(
                 _lib.ptr(input), _lib.ptr(weight), _lib.ptr(bias) if ctx.with_bias else None, _lib.ptr(offset),
                 _lib.ptr(output), _lib.ptr(ws), ws_bytes, g, _lib.current_stream(input.device)))
-        ctx.columns = ws if (needs_grad and SAVE_COLUMNS) else None
+        ctx.columns = ws if (needs_grad and SAVE_COLUMNS and not _backward_16bit_covers(ctx.dtype, g)) else None
         return output if ctx.dtype == cd else output.to(ctx.dtype)
 
     @staticmethod
@@ -402,7 +409,7 @@ class ModulatedDeformConvFunction(Function):
             _lib.check(_entry("ddcn_modulated_deform_conv_forward", cd)(
                 _lib.ptr(input), _lib.ptr(weight), _lib.ptr(bias) if ctx.with_bias else None, _lib.ptr(offset),
                 _lib.ptr(mask), _lib.ptr(output), _lib.ptr(ws), ws_bytes, g, _lib.current_stream(input.device)))
-        ctx.columns = ws if (needs_grad and SAVE_COLUMNS) else None
+        ctx.columns = ws if (needs_grad and SAVE_COLUMNS and not _backward_16bit_covers(ctx.dtype, g)) else None
         return output if ctx.dtype == cd else output.to(ctx.dtype)
 
     @staticmethod
@@ -598,6 +605,17 @@ def _autocast_view(tensors):
                  for t in tensors)
 
 
+def _autocast_fp32_view(tensors):
+    """For the Functions WITHOUT native 16-bit kernels (the mask branch of the DDCN layer, the depth-aware conv): under
+    torch.autocast every floating CUDA tensor of the call is taken to float32 (the `custom_fwd(cast_inputs=torch.float32)`
+    pattern) -- depth and the fp32 parameters keep their mantissa, no convert-in / convert-out kernels run inside the
+    Function -- and only the result is cast to the autocast dtype.  -> (tensors, autocast dtype | None)."""
+    if not torch.is_autocast_enabled("cuda"):
+        return tensors, None
+    return tuple(t.float() if isinstance(t, torch.Tensor) and t.is_cuda and t.is_floating_point()
+                 and t.dtype in (torch.bfloat16, torch.float16) else t for t in tensors), torch.get_autocast_dtype("cuda")
+
+
 def _inference_view(tensors):
     """Inside Function.forward a Parameter looks the same with and without torch.no_grad() (requires_grad stays
     True), so the reference saves its tensors for a backward that can never come.  The functional aliases below hand
@@ -625,8 +643,10 @@ def modulated_deform_conv(input, offset, mask, weight, bias=None, stride=1, padd
 
 def depthaware_conv(input, depth, weight, bias=None, stride=1, padding=0, dilation=1, groups=1):
     """`DepthawareConvFunction.apply` (PY:228) with the reference's positional argument order."""
-    input, depth, weight, bias = _inference_view(_autocast_view((input, depth, weight, bias)))
-    return DepthawareConvFunction.apply(input, depth, weight, bias, stride, padding, dilation, groups)
+    (input, depth, weight, bias), dt = _autocast_fp32_view((input, depth, weight, bias))
+    input, depth, weight, bias = _inference_view((input, depth, weight, bias))
+    out = DepthawareConvFunction.apply(input, depth, weight, bias, stride, padding, dilation, groups)
+    return out if dt is None else out.to(dt)
 
 
 class _DcnConvBase(nn.Module):
@@ -778,9 +798,13 @@ class DepthDeformConvPack(ModulatedDeformConv):
         k2x2 = 2 * self.kernel_size[0] * self.kernel_size[1]
         mask_offset = offset if self.deformable_groups == 1 else offset[:, :k2x2].contiguous()
         cm = self.conv_mask
-        depth_v, mask_offset, cm_weight, cm_bias = _inference_view(_autocast_view((depth, mask_offset, cm.weight, cm.bias)))
+        # no 16-bit kernels for this branch: under autocast it computes in fp32 on fp32 views, only the mask is cast
+        branch, dt = _autocast_fp32_view((depth, mask_offset, cm.weight, cm.bias))
+        depth_v, mask_offset, cm_weight, cm_bias = _inference_view(branch)
         mask = _DeformConvSigmoidFunction.apply(depth_v, mask_offset, cm_weight, cm_bias, cm.stride, cm.padding,
                                                 cm.dilation, cm.groups, cm.deformable_groups)
+        if dt is not None:
+            mask = mask.to(dt)
         self.offset, self.mask = offset, mask
         return modulated_deform_conv(x, offset, mask, self.weight, self.bias,
                                      self.stride, self.padding, self.dilation,

@@ -94,8 +94,8 @@ def test_train_cli_runs_and_resumes(tmp_path):
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
     base = [sys.executable, os.path.join(ROOT, "tools", "train.py"), "danet_r50_depthdeform", "--crop", "65", "97",
             "--imgs_per_gpu", "1", "--log_interval", "1", "--seed", "3"]
-    r = subprocess.run(base + ["--iters", "2", "--work_dir", str(tmp_path)], env=env, capture_output=True, text=True,
-                       timeout=600)
+    r = subprocess.run(base + ["--iters", "2", "--max_iters", "3", "--work_dir", str(tmp_path)], env=env,
+                       capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     logs = [json.loads(l) for l in r.stdout.splitlines() if l.startswith("{")]
     assert [l["iter"] for l in logs if "iter" in l] == [1, 2] and logs[-1]["checkpoint"].endswith("iter_2.pth")
@@ -104,3 +104,12 @@ def test_train_cli_runs_and_resumes(tmp_path):
     assert r2.returncode == 0, r2.stderr[-2000:]
     logs2 = [json.loads(l) for l in r2.stdout.splitlines() if l.startswith("{")]
     assert logs2[0]["iter"] == 3 and logs2[0]["loss"] == logs2[0]["loss"]
+    # the resumed run continues on the first run's polynomial (schedule length kept in the checkpoint, as mmcv's runner
+    # keeps total_epochs): its learning rate at iteration 3 is the one of an uninterrupted 3-iteration run
+    r3 = subprocess.run(base + ["--iters", "3"], env=env, capture_output=True, text=True, timeout=600)
+    assert r3.returncode == 0, r3.stderr[-2000:]
+    logs3 = [json.loads(l) for l in r3.stdout.splitlines() if l.startswith("{") and "iter" in l]
+    assert [l["iter"] for l in logs3] == [1, 2, 3]
+    assert logs2[0]["lr"] == pytest.approx(logs3[2]["lr"], rel=1e-12)
+    assert [l["lr"] for l in logs if "iter" in l] == pytest.approx([l["lr"] for l in logs3[:2]], rel=1e-12)
+    assert logs3[2]["lr"] == pytest.approx(0.00025 * (1 - 2 / 3) ** 0.9, rel=1e-9)

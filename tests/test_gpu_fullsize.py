@@ -167,3 +167,97 @@ def test_full_size_16bit_training_step_native_against_fp32_kernels(dtype, monkey
     for name, u, v in zip(("out", "gx", "goff", "gmask", "gw"), a, b):
         assert u.dtype == dtype and torch.isfinite(u.float()).all(), name
         assert cases.relerr(u.double().cpu().numpy(), v.double().cpu().numpy()) <= tol, name
+
+
+# ---------------------------------------------------------------- 16-bit training at the R101 layer shapes, batch 8
+def test_16bit_training_r101_layer_shapes_batch8_after_a_smaller_call(monkeypatch):
+    """The three DDCN layer shapes of BASELINE configs[2] (DDCN-R101, 769x769, batch 8: layer2's stride-2 layer 193x193 ->
+    97x97 at C = 128, layer3 at C = 256 dil 2, layer4 at C = 512 dil 4) in ONE process, after a smaller call, bf16 forward
+    and backward (native 16-bit kernels, G3's chain on the side stream) against the same tensors through the fp32 kernels.
+    Zero offsets and mask 0.5 for the first shape (what the model's zero-initialised offset convolutions feed), raw
+    randn offsets for the others.  The half instantiation of every reference kernel: deform_conv_cuda_kernel.cu:258,
+    352, 450."""
+    dcn = importlib.import_module("semantic-segmentation_amd.dcn.deform_conv")
+    shapes = [  # N, C, H, W, stride, dil, sigma
+        (1, 128, 25, 33, 2, 1, 2.0),          # the smaller call first
+        (8, 128, 193, 193, 2, 1, 0.0),
+        (8, 256, 97, 97, 1, 2, 2.0),
+        (8, 512, 97, 97, 1, 4, 2.0),
+    ]
+    gen = torch.Generator(device="cpu").manual_seed(5)
+    for N, C, H, W, stride, dil, sigma in shapes:
+        Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1            # pad = dil, 3x3
+        x = torch.randn(N, C, H, W, generator=gen)
+        w = (torch.rand(C, C, 3, 3, generator=gen) * 2 - 1) / ((C * 9) ** 0.5)
+        off = torch.randn(N, 18, Ho, Wo, generator=gen) * sigma
+        mask = torch.sigmoid(torch.randn(N, 9, Ho, Wo, generator=gen)) if sigma else torch.full((N, 9, Ho, Wo), 0.5)
+        gout = torch.randn(N, C, Ho, Wo, generator=gen)
+
+        def run(native):
+            monkeypatch.setattr(dcn, "TRAIN16_NATIVE", native)
+            t = [v.to(DEV).to(torch.bfloat16).requires_grad_(True) for v in (x, off, mask, w)]
+            out = pkg.modulated_deform_conv(t[0], t[1], t[2], t[3], None, stride, dil, dil, 1, 1)
+            out.backward(gout.to(DEV).to(torch.bfloat16))
+            torch.cuda.synchronize()
+            return [out.detach()] + [v.grad for v in t]
+        a, b = run(True), run(False)
+        for name, u, v in zip(("out", "gx", "goff", "gmask", "gw"), a, b):
+            assert u.dtype == torch.bfloat16 and torch.isfinite(u.float()).all(), (name, N, C, H)
+            assert cases.relerr(u.double().cpu().numpy(), v.double().cpu().numpy()) <= 1.5e-2, (name, N, C, H)
+        del a, b
+        torch.cuda.empty_cache()
+
+
+# ---------------------------------------------------------------- the DDCN layer under torch.autocast
+@pytest.mark.parametrize("C,H,W,stride,dil", [(256, 97, 97, 1, 2), (128, 193, 193, 2, 1)], ids=["layer3", "layer2_s2"])
+def test_ddcn_layer_under_autocast_at_r101_geometry(C, H, W, stride, dil):
+    """DepthDeformConvPack as the model builds it (zero-initialised offset / mask convolutions -> exactly zero offsets,
+    mask 0.5; conv_mask with bias) under torch.autocast(bfloat16), batch 8, at R101 layer geometries: forward and backward
+    against the same layer in fp32, to a bf16 output tolerance.  Main op: native 16-bit kernels; mask branch: fp32
+    kernels on fp32 views (no 16-bit kernels exist for it)."""
+    torch.manual_seed(3)
+    layer = pkg.DepthDeformConvPack(C, C, 3, stride=stride, padding=dil, dilation=dil, deformable_groups=1, bias=False,
+                                    depth_channels=C // 2).to(DEV)
+    with torch.no_grad():       # small non-zero offsets so that every branch carries gradient
+        layer.conv_offset.weight.normal_(0, 0.002)
+        layer.conv_mask.weight.normal_(0, 0.01)
+        layer.conv_mask.bias.fill_(0.1)
+    x = torch.randn(8, C, H, W, device=DEV)
+    depth = torch.randn(8, C // 2, H, W, device=DEV)
+    res = []
+    for amp in (False, True):
+        layer.zero_grad(set_to_none=True)
+        xi, di = x.clone().requires_grad_(True), depth.clone().requires_grad_(True)
+        with torch.autocast("cuda", dtype=torch.bfloat16, enabled=amp):
+            out = layer(xi, di)
+            assert out.dtype == (torch.bfloat16 if amp else torch.float32)
+            if amp:
+                assert layer.mask.dtype == torch.bfloat16
+            loss = out.float().square().mean()
+        loss.backward()
+        torch.cuda.synchronize()
+        res.append([out.detach().float(), xi.grad, di.grad, layer.weight.grad.clone(), layer.conv_mask.weight.grad.clone(),
+                    layer.conv_offset.weight.grad.clone()])
+    for name, a, b in zip(("out", "gx", "gdepth", "gw", "gw_mask", "gw_offset"), res[1], res[0]):
+        assert a.dtype == torch.float32 and torch.isfinite(a).all(), name
+        tol = 0.1 if name == "gw_offset" else 3e-2      # the offset gradient is discontinuous at integer coordinates
+        assert cases.relerr(a.double().cpu().numpy(), b.double().cpu().numpy()) <= tol, name
+
+
+def test_depthaware_conv_under_autocast_computes_in_fp32():
+    """DepthawareConv has no 16-bit kernels: under autocast its inputs are taken to float32 (depth keeps its mantissa --
+    the op's weights are exp(-|depth difference|)) and only the result is rounded to the autocast dtype."""
+    torch.manual_seed(4)
+    conv = pkg.DepthawareConv(32, 48, 3, padding=2, dilation=2).to(DEV)
+    x = torch.randn(2, 32, 41, 37, device=DEV, requires_grad=True)
+    depth = torch.rand(2, 1, 41, 37, device=DEV) * 4
+    ref = conv(x, depth)
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        out = conv(x.bfloat16(), depth.bfloat16().float() + 2.0 ** -12)     # a depth bf16 cannot hold
+        out32 = conv(x, depth)
+    assert out.dtype == torch.bfloat16 and out32.dtype == torch.bfloat16
+    # fp32 inputs under autocast: exactly the fp32 result, rounded once
+    assert torch.equal(out32, ref.to(torch.bfloat16))
+    (g,) = torch.autograd.grad(out32.float().sum(), x)
+    (g_ref,) = torch.autograd.grad(ref.sum(), x)
+    assert cases.relerr(g.cpu().numpy(), g_ref.cpu().numpy()) <= 1e-6

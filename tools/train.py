@@ -44,7 +44,10 @@ def parse_args(argv=None):
     parser.add_argument("--launcher", choices=["none", "pytorch", "slurm", "mpi"], default="none", help="job launcher")
     parser.add_argument("--local_rank", type=int, default=0)
     parser.add_argument("--autoscale-lr", action="store_true", help="scale lr with the number of gpus (lr * gpus / 8)")
-    parser.add_argument("--iters", type=int, default=20, help="training iterations (the reference counts epochs)")
+    parser.add_argument("--iters", type=int, default=20, help="training iterations of THIS run (the reference counts epochs)")
+    parser.add_argument("--max_iters", type=int, default=None,
+                        help="length of the whole poly schedule (the reference's total_epochs): fixed across --resume_from, "
+                             "stored in the checkpoint; default: --iters of the first run")
     parser.add_argument("--crop", type=int, nargs=2, default=None, metavar=("H", "W"), help="override the crop size")
     parser.add_argument("--imgs_per_gpu", type=int, default=None)
     parser.add_argument("--log_interval", type=int, default=10)
@@ -100,12 +103,16 @@ def main(argv=None):
     if distributed and world > 1 and cfg["norm"] == "SyncBN":
         model = torch.nn.SyncBatchNorm.convert_sync_batchnorm(model)
     opt = callers.build_optimizer(model, lr=lr)
-    start = 0
+    start, max_iters = 0, args.max_iters
     if args.resume_from:
         ck = torch.load(args.resume_from, map_location=dev, weights_only=True)
         model.load_state_dict(ck["state_dict"])
         opt.load_state_dict(ck["optimizer"])
         start = int(ck["meta"]["iter"])
+        # the schedule's length is the first run's (mmcv's runner keeps total_epochs across resume): the learning rate
+        # continues on the SAME polynomial instead of restarting a new one over start + iters
+        if max_iters is None and ck["meta"].get("max_iters"):
+            max_iters = int(ck["meta"]["max_iters"])
     reducer = callers.OverlappedGradReducer(model) if world > 1 else None
     g = torch.Generator().manual_seed(1234 + rank)
 
@@ -116,9 +123,13 @@ def main(argv=None):
                     gt_label=label.to(dev))
 
     total = start + args.iters
+    if max_iters is None:
+        max_iters = total
+    total = min(total, max_iters)                       # the schedule ends at max_iters (lr reaches 0 there)
     t0 = time.perf_counter()
+    loss = None
     for it in range(start, total):
-        loss = callers.train_step(model, opt, batch(), it, total, ignore_index=255, reducer=reducer)
+        loss = callers.train_step(model, opt, batch(), it, max_iters, ignore_index=255, reducer=reducer)
         if rank == 0 and ((it + 1) % args.log_interval == 0 or it + 1 == total):
             torch.cuda.synchronize()
             dt = time.perf_counter() - t0
@@ -129,7 +140,7 @@ def main(argv=None):
         os.makedirs(args.work_dir, exist_ok=True)
         path = os.path.join(args.work_dir, "iter_%d.pth" % total)
         torch.save({"state_dict": model.state_dict(), "optimizer": opt.state_dict(),
-                    "meta": {"iter": total, "config": args.config}}, path)
+                    "meta": {"iter": total, "max_iters": max_iters, "config": args.config}}, path)
         print(json.dumps({"checkpoint": path}), flush=True)
     if distributed:
         dist.barrier()
