@@ -60,13 +60,20 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t s9_rsrc(const void *base, long
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(base), 0, n, 0x00020000);
 }
 
-// FX: the footprint is kept as 32-bit fixed point, two channels per 64-bit LDS word, and accumulated with ds_add_u64
-// (19 cycles per wave instruction for two channels against 2 x 23.5 for ds_add_f64).  Per chunk the workgroup takes the
-// largest |column value x mask| it is about to add, gmax < 2^e, and scales by 2^(19-e): every contribution is below
-// 2^19 in magnitude, and since the four corner weights of a sample sum to 1 a cell can collect at most
-// 256 pixels x 9 taps < 2^12 of them, so a field never leaves 31 bits.  Adding (hi << 32) + lo as ONE signed 64-bit
-// number is exact for both fields (the borrow of a negative low part is undone when the word is decoded as
-// lo = int32(word), hi = (word - lo) >> 32).  Resolution: 2^-19 of the chunk's largest column value per add.
+// FX (the default for 2- and 4-channel chunks): the footprint is kept as 32-bit fixed point, two channels per 64-bit LDS
+// word, and accumulated with ds_add_u64 (19 cycles per wave instruction for two channels against 2 x 19 for the exact
+// 64-bit fixed point XQ and 2 x 23.5 for ds_add_f64): half the LDS atomics, which are what bounds this kernel.
+//   scale     per chunk the workgroup takes the largest |column value x mask| it is about to add, gmax < 2^e.
+//   headroom  a field must hold every sum a cell can collect.  The workgroup counts, ONCE, how many of its samples have
+//             their (hl, wl) corner in each patch cell (one ds_add_u32 per sample); a cell is touched by the samples
+//             based at itself and at its left / upper / upper-left neighbour, and each adds at most gmax (a corner
+//             weight is <= 1), so with cmax = the largest such 4-cell count, cmax < 2^hb, contributions scaled by
+//             2^(sh - e), sh = 30 - hb, keep every field below cmax * (2^sh + 1/2) < 2^31: no overflow for ANY offset
+//             field (all 2304 samples of a tile on one cell: sh = 18), and 2^-24 ... 2^-26 of the chunk's largest value
+//             per add for ordinary ones (cmax 16 ... 64) -- the resolution of an fp32 atomic add.
+//   packing   adding (hi << 32) + lo as ONE signed 64-bit number is exact for both fields (the borrow of a negative low
+//             part is undone when the word is decoded as lo = int32(word), hi = (word - lo) >> 32).
+// Integer sums do not depend on the order of the adds: the LDS part of the scatter is deterministic.
 // A non-finite column value cannot be represented: the chunk then writes NaN to every cell it could have touched.
 // SKB > 0: the column gradients are never in memory.  For a deformable convolution with few (<= SKB) output channels
 // -- the DDCN layer's 9-channel mask branch -- gcol = W^T * grad_out is a 9-term dot product per element: each lane keeps
@@ -88,7 +95,7 @@ __device__ __forceinline__ void tile9_body(const Tile9Args &a, const PatchGeom p
 {
     static_assert(!XQ || (!FX && SKB == 0), "exact fixed point: its own mode");
     constexpr bool MAXQ = FX || XQ;        // modes that need the chunk's largest |value|
-    static_assert(!FX || SC == 4, "fixed-point footprint packs channel pairs of a 4-channel chunk");
+    static_assert(!FX || SC == 4 || SC == 2, "fixed-point footprint packs channel pairs");
     static_assert(SKB == 0 || (SC == 4 && !FX && !MOD && SKB % 4 == 0), "direct mode: plain op, 4-channel chunks");
     typedef float xvec __attribute__((ext_vector_type(SC)));
     typedef unsigned long long u64;
@@ -96,6 +103,7 @@ __device__ __forceinline__ void tile9_body(const Tile9Args &a, const PatchGeom p
     constexpr int GB = FX ? 4 : 8;                                           // footprint bytes per channel and cell
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     __shared__ unsigned s_max[2];                                            // FX: bit pattern of gmax, per chunk parity
+    __shared__ unsigned s_cmax;                                              // FX: largest 4-cell sample count of the patch
     double *gs = reinterpret_cast<double *>(smem_raw);                       // [SC][RS]: a wave's 64 cells -> 128 banks
     u64 *gq = reinterpret_cast<u64 *>(smem_raw);                             // FX: [SC/2][RS], channels (2j, 2j+1)
     xvec *xs = reinterpret_cast<xvec *>(smem_raw + (size_t)pg.RS * SC * GB);   // [RS][SC]
@@ -238,7 +246,36 @@ __device__ __forceinline__ void tile9_body(const Tile9Args &a, const PatchGeom p
         return v;
     };
 
+    int fx_sh = 19;                 // FX: contributions are scaled to below 2^fx_sh
     if (FX) {
+        // headroom from the workgroup's own samples (see the FX note above); the counters borrow the footprint's memory
+        unsigned *cnt32 = reinterpret_cast<unsigned *>(smem_raw);
+        for (int i = t; i < pg.RS; i += ST) cnt32[i] = 0u;
+        if (t == 0) s_cmax = 0u;
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < K2; ++k)
+            if (cell[k] >= 0) atomicAdd(&cnt32[cell[k]], 1u);
+        __syncthreads();
+        unsigned cm = 0u;
+#pragma unroll
+        for (int j = 0; j < NCELL; ++j) {
+            const int i = t + ST * j;
+            if (i < pg.RS) {
+                const int rr = i / pg.RW, rc = i - rr * pg.RW;
+                unsigned c4 = cnt32[i];
+                if (rc > 0) c4 += cnt32[i - 1];
+                if (rr > 0) c4 += cnt32[i - pg.RW];
+                if (rr > 0 && rc > 0) c4 += cnt32[i - pg.RW - 1];
+                cm = max(cm, c4);
+            }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) cm = max(cm, (unsigned)__shfl_xor((int)cm, o));
+        if ((t & 63) == 0 && cm) atomicMax(&s_cmax, cm);
+        __syncthreads();
+        fx_sh = 30 - (32 - __clz((int)s_cmax));          // cmax < 2^hb, hb = 32 - clz(cmax); cmax <= 2304 -> fx_sh >= 18
+        __syncthreads();                                  // the counters are dead: the footprint takes their place
         for (int i = t; i < pg.RS * SC / 2; i += ST) gq[i] = 0ull;
         if (t < 2) s_max[t] = 0u;
     } else if (XQ) {
@@ -286,7 +323,7 @@ __device__ __forceinline__ void tile9_body(const Tile9Args &a, const PatchGeom p
         const int c0 = cg0 + ch * SC;
         const bool more = ch + 1 < nchunks;
         const unsigned pvn = more ? pvo : SOOB;
-        int fx_e = 0;               // FX: contributions are scaled by 2^(19 - fx_e)
+        int fx_e = 0;               // FX: contributions are scaled by 2^(fx_sh - fx_e)
         bool fx_bad = false;
         if (MAXQ) {
             const float gmax = __uint_as_float(s_max[ch & 1]);
@@ -315,7 +352,7 @@ __device__ __forceinline__ void tile9_body(const Tile9Args &a, const PatchGeom p
                     for (int cc = 0; cc < SC; ++cc) {
                         const float gc = gcv[k][cc];
                         S1[k] += gc * a1[cc]; S2[k] += gc * a2[cc]; S3[k] += gc * a3[cc]; S4[k] += gc * a4[cc];
-                        tgs[cc] = ldexpf(MOD ? gc * fm[k] : gc, 19 - fx_e);
+                        tgs[cc] = ldexpf(MOD ? gc * fm[k] : gc, fx_sh - fx_e);
                     }
                     if (!fx_bad) {
                         u64 *q1 = gq + ci, *q3 = gq + ci + pg.RW;
@@ -378,7 +415,7 @@ __device__ __forceinline__ void tile9_body(const Tile9Args &a, const PatchGeom p
         // C. flush the footprint (one global atomic per touched in-image cell), re-zero, install the next patch
         if (FX) {
             if (t == 0) s_max[ch & 1] = 0u;          // everyone has read it; it is published again two chunks on
-            const float inv = ldexpf(1.f, fx_e - 19);
+            const float inv = ldexpf(1.f, fx_e - fx_sh);
 #pragma unroll
             for (int j = 0; j < NCELL; ++j) {
                 const int i = t + ST * j;
@@ -547,7 +584,9 @@ constexpr int ADAPT_STEPS = 8;         // candidate margins a.M + 2 * j
 
 // SCN / SCW: channels per chunk of the planner's and of the wide footprint: 4 / 2 in an 80 KiB allocation (two workgroups
 // per CU), 2 / 1 in 40 KiB and 168 VGPRs (three per CU: the variant that runs beside a GEMM in the two-stream backward).
-template <bool MOD, int NCELL, int SCN, int SCW>
+// FXA: packed 32-bit fixed-point footprints (two channels per LDS atomic) wherever a body has channel pairs; else (and for the
+// 1-channel wide body) the exact 64-bit fixed point.
+template <bool MOD, int NCELL, int SCN, int SCW, bool FXA>
 __global__ __launch_bounds__(ST, SCN == 4 ? 2 : DDCN_S9_WPS) void col2im_coord_tile9_adaptive_kernel(Tile9Args a)
 {
     __shared__ int s_esc[ADAPT_STEPS];
@@ -609,11 +648,12 @@ __global__ __launch_bounds__(ST, SCN == 4 ? 2 : DDCN_S9_WPS) void col2im_coord_t
     }
     best = __builtin_amdgcn_readfirstlane(best);      // the same in every lane: make the branch a scalar one
     __syncthreads();
+    constexpr bool FXW = FXA && SCW >= 2;
     if (best == 0) {
-        tile9_body<MOD, NCELL, SCN, false, 0, true>(a, PatchGeom{a.M, a.RH, a.RW, a.RS});
+        tile9_body<MOD, NCELL, SCN, FXA, 0, !FXA>(a, PatchGeom{a.M, a.RH, a.RW, a.RS});
     } else {
         const int M = a.M + 2 * best, RH = RH0 + 2 * M, RW = RW0 + 2 * M;
-        tile9_body<MOD, NCELL_WIDE, SCW, false, 0, true>(a, PatchGeom{M, RH, RW, RH * RW});
+        tile9_body<MOD, NCELL_WIDE, SCW, FXW, 0, !FXW>(a, PatchGeom{M, RH, RW, RH * RW});
     }
 }
 
@@ -713,11 +753,13 @@ int launch_col2im_coord_tile9(const float *gcol, const float *x, const float *of
     const long nwg = (long)a.tiles * a.groups;
     if (nwg > 0x7fffffffL || g.N > 65535) return fail(DDCN_ERR_UNSUPPORTED, "col2im_coord_tile9: grid too large");
     dim3 grid((unsigned)nwg, 1, g.N);
-    // opt-in (read per call so that tests can switch it): 15-25 % faster, grad_input accurate to ~1e-5 instead of ~1e-7
+    // Footprint format (read per call so that tests can switch it): packed 32-bit fixed point with per-workgroup headroom
+    // (FX, the default: half the LDS atomics), DDCN_SCATTER_FX=0 -> exact 64-bit fixed point (XQ), and with DDCN_SCATTER_XQ=0
+    // on top doubles.  The direct (few-output-channel) mode keeps doubles.
     const char *env_fx = getenv("DDCN_SCATTER_FX");
-    const bool fx = env_fx && atoi(env_fx) != 0 && SC == 4 && !direct;
+    const bool fx = !(env_fx && atoi(env_fx) == 0) && !direct && wide_m == 0;
     const char *env_xq = getenv("DDCN_SCATTER_XQ");
-    const bool xq = !fx && !direct && (wide_m > 0 || !(env_xq && atoi(env_xq) == 0));   // default; DDCN_SCATTER_XQ=0: double footprint
+    const bool xq = !fx && !direct && (wide_m > 0 || !(env_xq && atoi(env_xq) == 0));
     const size_t smem = (size_t)a.RS * (fx ? 8 : 12) * SC + (direct ? (size_t)4 * 9 * SKB_MAX * sizeof(float) : 0);
     const int ncell = (a.RS + ST - 1) / ST;
     bool ok_lds = true;
@@ -745,8 +787,10 @@ int launch_col2im_coord_tile9(const float *gcol, const float *x, const float *of
     do {                                                                                                         \
         if (xq && mask) DDCN_S9_LAUNCH_XQ(true, NC);                                                             \
         else if (xq) DDCN_S9_LAUNCH_XQ(false, NC);                                                               \
-        else if (mask && fx) DDCN_S9_LAUNCH2(true, NC, 4, true);                                                 \
-        else if (fx) DDCN_S9_LAUNCH2(false, NC, 4, true);                                                        \
+        else if (mask && fx && SC == 4) DDCN_S9_LAUNCH2(true, NC, 4, true);                                      \
+        else if (fx && SC == 4) DDCN_S9_LAUNCH2(false, NC, 4, true);                                             \
+        else if (mask && fx) DDCN_S9_LAUNCH2(true, NC, 2, true);                                                 \
+        else if (fx) DDCN_S9_LAUNCH2(false, NC, 2, true);                                                        \
         else if (mask && SC == 4) DDCN_S9_LAUNCH2(true, NC, 4, false);                                           \
         else if (mask) DDCN_S9_LAUNCH2(true, NC, 2, false);                                                      \
         else if (SC == 4) DDCN_S9_LAUNCH2(false, NC, 4, false);                                                  \
@@ -764,31 +808,38 @@ int launch_col2im_coord_tile9(const float *gcol, const float *x, const float *of
     int Mw_max = 0;
     size_t smem_ad = smem;
     const size_t ad_cap = SC == 4 ? S9_LDS_MAX : S9_LDS_MAX / 2;
-    if (env_ad && xq && wide_m == 0 && ncell <= 8) {
+    // bytes per cell of the wide body's footprint + patch: SC/2 channels, packed when they still come in pairs
+    const size_t wide_cell = (fx && SC == 4) ? 8 * 2 : (size_t)12 * (SC / 2);
+    if (env_ad && (xq || fx) && wide_m == 0 && ncell <= 8) {
         const int RH0 = a.RH - 2 * a.M, RW0 = a.RW - 2 * a.M;
         for (int M = a.M + 2; M <= a.M + 2 * (ADAPT_STEPS - 1); M += 2) {
             const long cells = (long)(RH0 + 2 * M) * (RW0 + 2 * M);
-            if (cells > NCELL_WIDE * ST || cells * 12 * (SC / 2) > (long)ad_cap) break;
+            if (cells > NCELL_WIDE * ST || cells * (long)wide_cell > (long)ad_cap) break;
             Mw_max = M;
-            smem_ad = std::max(smem, (size_t)cells * 12 * (SC / 2));
+            smem_ad = std::max(smem, (size_t)cells * wide_cell);
         }
     }
     a.Mw_max = Mw_max;
     static const int env_esc = getenv("DDCN_SCATTER_ESC_CELLS") ? atoi(getenv("DDCN_SCATTER_ESC_CELLS")) : ESC_CELLS;
     a.esc_cells = env_esc;
-#define DDCN_S9_LAUNCH_AD(MOD, NC, SCN, SCW)                                                                     \
+#define DDCN_S9_LAUNCH_AD(MOD, NC, SCN, SCW, FXV)                                                                \
     do {                                                                                                         \
         static std::atomic<uint64_t> raised{0};                                                                  \
-        ok_lds = raise_lds_limit((const void *)&col2im_coord_tile9_adaptive_kernel<MOD, NC, SCN, SCW>, S9_LDS_MAX, raised); \
+        ok_lds = raise_lds_limit((const void *)&col2im_coord_tile9_adaptive_kernel<MOD, NC, SCN, SCW, FXV>, S9_LDS_MAX, raised); \
         if (ok_lds)                                                                                              \
-            hipLaunchKernelGGL((col2im_coord_tile9_adaptive_kernel<MOD, NC, SCN, SCW>), grid, dim3(ST), smem_ad, stream, a); \
+            hipLaunchKernelGGL((col2im_coord_tile9_adaptive_kernel<MOD, NC, SCN, SCW, FXV>), grid, dim3(ST), smem_ad, stream, a); \
+    } while (0)
+#define DDCN_S9_LAUNCH_ADF(MOD, NC, SCN, SCW)                                                                    \
+    do {                                                                                                         \
+        if (fx) DDCN_S9_LAUNCH_AD(MOD, NC, SCN, SCW, true);                                                      \
+        else DDCN_S9_LAUNCH_AD(MOD, NC, SCN, SCW, false);                                                        \
     } while (0)
 #define DDCN_S9_LAUNCH_ADN(NC)                                                                                   \
     do {                                                                                                         \
-        if (mask && SC == 4) DDCN_S9_LAUNCH_AD(true, NC, 4, 2);                                                  \
-        else if (SC == 4) DDCN_S9_LAUNCH_AD(false, NC, 4, 2);                                                    \
-        else if (mask) DDCN_S9_LAUNCH_AD(true, NC, 2, 1);                                                        \
-        else DDCN_S9_LAUNCH_AD(false, NC, 2, 1);                                                                 \
+        if (mask && SC == 4) DDCN_S9_LAUNCH_ADF(true, NC, 4, 2);                                                 \
+        else if (SC == 4) DDCN_S9_LAUNCH_ADF(false, NC, 4, 2);                                                   \
+        else if (mask) DDCN_S9_LAUNCH_ADF(true, NC, 2, 1);                                                       \
+        else DDCN_S9_LAUNCH_ADF(false, NC, 2, 1);                                                                \
     } while (0)
     if (Mw_max > 0) {
         if (ncell <= 2) DDCN_S9_LAUNCH_ADN(2);
@@ -806,6 +857,7 @@ int launch_col2im_coord_tile9(const float *gcol, const float *x, const float *of
     else if (ncell <= 8) DDCN_S9_LAUNCH(8);
     else { if (mask) DDCN_S9_LAUNCH_XQ2(true, 14, 2); else DDCN_S9_LAUNCH_XQ2(false, 14, 2); }
 #undef DDCN_S9_LAUNCH_AD
+#undef DDCN_S9_LAUNCH_ADF
 #undef DDCN_S9_LAUNCH_ADN
 #undef DDCN_S9_LAUNCH_DIRECT
 #undef DDCN_S9_LAUNCH2

@@ -218,8 +218,12 @@ def test_ddcn_layer_under_autocast_at_r101_geometry(C, H, W, stride, dil):
     torch.manual_seed(3)
     layer = pkg.DepthDeformConvPack(C, C, 3, stride=stride, padding=dil, dilation=dil, deformable_groups=1, bias=False,
                                     depth_channels=C // 2).to(DEV)
-    with torch.no_grad():       # small non-zero offsets so that every branch carries gradient
-        layer.conv_offset.weight.normal_(0, 0.002)
+    with torch.no_grad():
+        # Offsets from the bias alone (zero weights, as the model initialises them), at values bf16 holds exactly and
+        # away from the integers: both runs then sample the SAME cells.  (d/d(offset) is discontinuous at integer
+        # coordinates; offsets that differ by a bf16 rounding flip cells there and the two runs legitimately disagree
+        # on those elements -- measured: 13 % of max|gx| with N(0, 0.002) offset weights.)
+        layer.conv_offset.bias.copy_((torch.randint(-8, 8, (18,)).float() + 0.5) / 8)
         layer.conv_mask.weight.normal_(0, 0.01)
         layer.conv_mask.bias.fill_(0.1)
     x = torch.randn(8, C, H, W, device=DEV)
@@ -238,10 +242,14 @@ def test_ddcn_layer_under_autocast_at_r101_geometry(C, H, W, stride, dil):
         torch.cuda.synchronize()
         res.append([out.detach().float(), xi.grad, di.grad, layer.weight.grad.clone(), layer.conv_mask.weight.grad.clone(),
                     layer.conv_offset.weight.grad.clone()])
+    errs = {}
     for name, a, b in zip(("out", "gx", "gdepth", "gw", "gw_mask", "gw_offset"), res[1], res[0]):
-        assert a.dtype == torch.float32 and torch.isfinite(a).all(), name
-        tol = 0.1 if name == "gw_offset" else 3e-2      # the offset gradient is discontinuous at integer coordinates
-        assert cases.relerr(a.double().cpu().numpy(), b.double().cpu().numpy()) <= tol, name
+        assert a.dtype == torch.float32 and bool(torch.isfinite(a).all()), name
+        errs[name] = float(cases.relerr(a.double().cpu().numpy(), b.double().cpu().numpy()))
+    print("autocast vs fp32 rel-err:", {k: "%.2e" % v for k, v in errs.items()})
+    tol = dict(out=3e-2, gw=3e-2, gw_mask=5e-2, gx=3e-2, gdepth=5e-2, gw_offset=5e-2)
+    bad = {k: v for k, v in errs.items() if not v <= tol[k]}
+    assert not bad, bad
 
 
 def test_depthaware_conv_under_autocast_computes_in_fp32():

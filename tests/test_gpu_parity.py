@@ -271,11 +271,17 @@ def test_direct_forward_with_sigmoid_matches_composition(geo):
         assert cases.relerr(got, ref.astype(np.float64)) <= BWD_TOL
 
 
+_FOOTPRINTS = {"fx": {}, "xq": {"DDCN_SCATTER_FX": "0"}, "f64": {"DDCN_SCATTER_FX": "0", "DDCN_SCATTER_XQ": "0"}}
+
+
+@pytest.mark.parametrize("mode", sorted(_FOOTPRINTS))
 @pytest.mark.parametrize("c", [cases.MEDIUM_CASES[0], cases.MEDIUM_CASES[1]], ids=lambda c: c["name"])
-def test_fixed_point_scatter_footprint_option(c, monkeypatch):
-    """DDCN_SCATTER_FX=1: the LDS footprint of the backward scatter as packed 32-bit fixed point (ds_add_u64, two
-    channels per atomic).  Same bar as the default path; a NaN in grad_output must still surface in grad_input."""
-    monkeypatch.setenv("DDCN_SCATTER_FX", "1")
+def test_scatter_footprint_formats(c, mode, monkeypatch):
+    """The LDS footprint of the backward scatter in its three formats: packed 32-bit fixed point with per-workgroup
+    headroom (the default: two channels per ds_add_u64), exact 64-bit fixed point (DDCN_SCATTER_FX=0) and doubles
+    (... DDCN_SCATTER_XQ=0).  Same bar for all; a NaN in grad_output must still surface in grad_input."""
+    for k, v in _FOOTPRINTS[mode].items():
+        monkeypatch.setenv(k, v)
     inp = cases.make_inputs(c)
     kw = cases.kwargs(c)
     r = _r32(inp)
@@ -288,6 +294,46 @@ def test_fixed_point_scatter_footprint_option(c, monkeypatch):
     bad["gout"][0, 0, 2, 3] = np.nan
     _, grads = _run_hip(c, bad)
     assert np.isnan(grads["gx"]).any()
+
+
+@pytest.mark.parametrize("scale", [1e-6, 1.0, 1e6], ids=["gout_1e-6", "gout_1", "gout_1e6"])
+def test_scatter_fixed_point_is_scale_free_and_as_accurate_as_fp32_atomics(scale):
+    """The packed fixed-point footprint scales every chunk by its own largest value (a power of two) and sizes its headroom
+    from the workgroup's own samples: grad_input must meet the bar for grad_output of any magnitude, and -- the point of the
+    per-workgroup headroom -- sit at fp32-rounding level, not at the 1e-5 of a worst-case (2304 samples per cell) scale."""
+    c = cases.C("fx_scale", N=2, Ci=32, Co=24, H=37, W=41, kh=3, kw=3, pad=2, dil=2, modulated=True, off_scale=2.0, seed=5)
+    inp = cases.make_inputs(c)
+    inp["gout"] = inp["gout"] * scale
+    r = _r32(inp)
+    exp = orc.deform_backward(r["x"], r["offset"], r["mask"], r["weight"], r["gout"], c["bias"], **cases.kwargs(c))
+    _, grads = _run_hip(c, inp)
+    for k, e in zip(("gx", "goff", "gmask", "gw"), exp[:4]):
+        assert cases.relerr(grads[k], e) <= BWD_TOL, (k, cases.relerr(grads[k], e))
+    assert cases.relerr(grads["gx"], exp[0]) <= 2e-6, cases.relerr(grads["gx"], exp[0])
+
+
+def test_scatter_fixed_point_headroom_when_every_sample_hits_one_cell():
+    """The adversarial offset field for a packed footprint: every sample of every pixel lands in the SAME bilinear cell, so
+    the tiles around it add 256 pixels x 9 taps into one LDS word per channel pair.  The headroom count sees that (2304
+    samples -> 12 bits) and the 32-bit fields cannot wrap: grad_input still meets the bar."""
+    c = cases.C("fx_pile", N=1, Ci=8, Co=8, H=24, W=24, kh=3, kw=3, pad=1, dil=1, modulated=True, off_scale=0.0, seed=9)
+    inp = cases.make_inputs(c)
+    Ho, Wo, K2 = cases.geometry(c)
+    off = np.zeros((1, 2 * K2, Ho, Wo), dtype=np.float64)
+    ty, tx = 11.25 + 2.0 ** -11, 12.5 + 2.0 ** -11
+    for k in range(K2):
+        i, j = divmod(k, 3)
+        hh = np.arange(Ho)[:, None] - 1 + i
+        ww = np.arange(Wo)[None, :] - 1 + j
+        off[0, 2 * k] = ty - hh
+        off[0, 2 * k + 1] = tx - ww
+    inp["offset"] = off
+    inp["gout"] = np.abs(inp["gout"]) + 0.5          # same sign: the sums really grow to ~2304 x the largest value
+    r = _r32(inp)
+    exp = orc.deform_backward(r["x"], r["offset"], r["mask"], r["weight"], r["gout"], c["bias"], **cases.kwargs(c))
+    _, grads = _run_hip(c, inp)
+    for k, e in zip(("gx", "goff", "gmask", "gw"), exp[:4]):
+        assert cases.relerr(grads[k], e) <= BWD_TOL, (k, cases.relerr(grads[k], e))
 
 
 def _fuzz_cases():
