@@ -299,6 +299,19 @@ def model_workload(args, world, rank, dev):
     devices = job_devices(dev, world)
     grad_bytes = sum(p.numel() * p.element_size() for p in model.parameters() if p.requires_grad)
     probe = allreduce_probe(dev, world, grad_bytes, iters=5) if world > 1 else None
+    # every bucket size of the overlapped reducer, alone: the per-message times and bus bandwidths behind the step time
+    # (one ring over xGMI is per-link bound, ~153 GB/s; all 7 links of a GPU give ~1 TB/s aggregate)
+    bucket_probe = None
+    if world > 1:
+        tmp = reducer or callers.OverlappedGradReducer(model)
+        sizes = [sum(p.numel() * p.element_size() for p in b) for b in tmp.buckets]
+        if reducer is None:
+            tmp.remove()
+        bucket_probe = []
+        for nbytes in sorted(set(sizes), reverse=True):
+            r = allreduce_probe(dev, world, nbytes, iters=3)
+            r["count"] = sizes.count(nbytes)
+            bucket_probe.append(r)
     if rank == 0:
         print(json.dumps({
             "metric": "train images/sec", "value": round(n * world * args.steps / dt, 3), "unit": "images/s",
@@ -317,7 +330,8 @@ def model_workload(args, world, rank, dev):
             "peak_mem_GB": round(torch.cuda.max_memory_allocated() / 2 ** 30, 2),
             "devices": devices,
             "allreduce": None if probe is None else {
-                "gradient": probe, "backend": "nccl (RCCL)" if args.backend == "nccl" else "gloo (rehearsal)",
+                "gradient": probe, "buckets": bucket_probe,
+                "backend": "nccl (RCCL)" if args.backend == "nccl" else "gloo (rehearsal)",
                 "distinct_devices": len({tuple(d[1:]) for d in devices})},
         }), flush=True)
 
@@ -532,6 +546,24 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
 
+    # the same step under the OTHER backward schedule (one stream <-> weight-gradient GEMM on a side stream beside the
+    # scatter), so that the line shows what the default buys; per-kernel rooflines below are timed one kernel at a time,
+    # which is what the one-stream schedule runs
+    dcn = importlib.import_module("semantic-segmentation_amd.dcn.deform_conv")
+    default_two = bool(dcn.TWO_STREAM_BACKWARD)
+    alt = None
+    if world == 1:
+        dcn.TWO_STREAM_BACKWARD = not default_two
+        for _ in range(max(1, args.warmup)):
+            step()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        torch.cuda.synchronize()
+        alt = (time.perf_counter() - t1) / args.steps * 1e3
+        dcn.TWO_STREAM_BACKWARD = default_two
+
     a = alg_numbers(w)
     images = w["N"] * world * args.steps
     devices = job_devices(dev, world)
@@ -547,11 +579,16 @@ def main():
                                "stride 1, pad=dil=%d, groups 1, dg 1, fwd+bwd" %
                                (w["N"], w["C"], w["Co"], w["H"], w["W"], w["dil"]),
                    "images_per_gpu": w["N"], "parallelism": "dp%d" % world,
-                   "alg_bytes_per_image": a["b_total"], "alg_flops_per_image": a["f_total"]},
+                   "alg_bytes_per_image": a["b_total"], "alg_flops_per_image": a["f_total"],
+                   "backward_schedule": "two streams (G3 beside the scatter)" if default_two else
+                                        "one stream: every kernel runs alone, in order"},
         "op_tflops": round(a["f_total"] * images / dt / 1e12, 2),
         "images_per_s": round(images / dt, 2),
         "devices": devices,
     }
+    if alt is not None:
+        line["ms_per_step_other_schedule"] = {"schedule": "one stream" if default_two else "two streams",
+                                              "ms_per_step": round(alt, 4)}
     if world > 1:
         # the layer's own exchange (grad_weight) and, for scale, the gradient of BASELINE configs[3]'s model
         # (DDCN-ResNet101 + DANet head: ~69 M fp32 parameters = 276 MB in one step)

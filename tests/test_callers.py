@@ -275,3 +275,79 @@ def test_overlapped_reducer_issues_buckets_in_order_with_rank_dependent_unused_p
             exp2[n] += p.grad / 2
     for n in exp2:
         assert torch.allclose(torch.from_numpy(acc[n]), exp2[n], atol=1e-6), n
+
+
+# ------------------------------------------------------------------ world size 4: uneven buckets, rank-dependent unused parameter
+class _Uneven(torch.nn.Module):
+    """Parameters of very different sizes (3 ... 4096 elements) so that a 2 KiB bucket limit yields buckets of one big
+    tensor next to buckets of several small ones; `skip` is used by the even ranks only."""
+
+    def __init__(self):
+        super().__init__()
+        torch.manual_seed(11)
+        self.big = torch.nn.Linear(64, 64)          # 4096 + 64
+        self.mid = torch.nn.Linear(64, 20)          # 1280 + 20
+        self.skip = torch.nn.Linear(64, 20)         # same shape, not used on odd ranks
+        self.small = torch.nn.ModuleList(torch.nn.Linear(20, 3) for _ in range(5))    # 5 x (60 + 3)
+
+    def forward(self, x, use_skip):
+        h = self.big(x)
+        y = self.mid(h)
+        if use_skip:
+            y = y + self.skip(h)
+        return sum(l(y) for l in self.small)
+
+
+def _uneven_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(1)
+    m = _Uneven()
+    red = callers.OverlappedGradReducer(m, bucket_size_mb=2048 / 2 ** 20)
+    sizes = [sum(p.numel() for p in b) for b in red.buckets]
+    g = torch.Generator().manual_seed(21)
+    x = torch.randn(world * 3, 64, generator=g)[3 * rank:3 * rank + 3]
+    orders = []
+    for it in range(2):                               # two iterations: the reducer resets itself in finish()
+        for p in m.parameters():
+            p.grad = None
+        m(x, use_skip=(rank % 2 == 0)).square().sum().backward()
+        red.finish()
+        orders.append(list(red.issued_order))
+    q.put((rank, sizes, orders, {n: p.grad.numpy().copy() for n, p in m.named_parameters()}))
+    dist.destroy_process_group()
+
+
+def test_overlapped_reducer_world4_uneven_buckets_and_rank_dependent_unused_parameter():
+    """The N-rank path beyond two ranks (detseg/core/utils/dist_utils.py:9-58 semantics: SUM, then / world): four gloo
+    ranks, buckets of uneven size, a layer that only the even ranks use.  Every rank must issue the same collectives in
+    the same order in both iterations and end with the mean of the four local gradients (missing = zero)."""
+    world = 4
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_uneven_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted((q.get(timeout=180) for _ in procs), key=lambda r: r[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    sizes = res[0][1]
+    assert len(sizes) >= 5 and max(sizes) >= 8 * min(sizes)              # uneven on purpose
+    assert all(r[1] == sizes for r in res)
+    order = list(range(len(sizes)))
+    assert all(r[2] == [order, order] for r in res)
+    m = _Uneven()
+    g = torch.Generator().manual_seed(21)
+    xs = torch.randn(world * 3, 64, generator=g)
+    exp = {n: torch.zeros_like(p) for n, p in m.named_parameters()}
+    for rank in range(world):
+        m.zero_grad(set_to_none=True)
+        m(xs[3 * rank:3 * rank + 3], use_skip=(rank % 2 == 0)).square().sum().backward()
+        for n, p in m.named_parameters():
+            if p.grad is not None:
+                exp[n] += p.grad / world
+    for r in res:
+        for n in exp:
+            assert torch.allclose(torch.from_numpy(r[3][n]), exp[n], rtol=1e-5, atol=1e-5), (r[0], n)

@@ -79,6 +79,10 @@ def test_bench_gpus2_model_workload_rehearsal_over_gloo():
     assert line["n_gpus"] == 2 and line["config"]["parallelism"] == "dp2" and line["config"]["norm"] == "BN"
     assert line["config"]["allreduce"].startswith("32 MiB buckets")
     assert line["allreduce"]["backend"].startswith("gloo") and line["allreduce"]["gradient"]["bytes"] > 100e6
+    # every bucket size of the reducer is timed alone: the sizes add up to the whole gradient
+    buckets = line["allreduce"]["buckets"]
+    assert sum(b["bytes"] * b["count"] for b in buckets) == line["allreduce"]["gradient"]["bytes"]
+    assert all(b["ms"] > 0 and b["bus_GBps"] > 0 for b in buckets)
     assert line["final_loss"] == line["final_loss"] and line["final_loss"] > 0
 
 
