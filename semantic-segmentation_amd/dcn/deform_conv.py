@@ -95,11 +95,17 @@ BF16_NATIVE = os.environ.get("DDCN_BF16_NATIVE", "1") != "0"
 
 
 # Saved-columns fp32 backward on two streams (ddcn_deform_conv_backward_saved_2s_f32): the weight-gradient GEMM runs on
-# a side stream beside the LDS-atomic-bound scatter.  DDCN_TWO_STREAM_BACKWARD=0 keeps everything on one stream.
-TWO_STREAM_BACKWARD = os.environ.get("DDCN_TWO_STREAM_BACKWARD", "1") != "0"
+# a side stream beside the LDS-atomic-bound scatter.  Opt-in since round 3 (DDCN_TWO_STREAM_BACKWARD=1): with the packed
+# fixed-point scatter (0.35 -> 0.31 ms alone) one stream is the faster schedule -- bench layer 2.449 vs 2.481 ms, DDCN-R101
+# step 465.3 vs 466.6 ms, DDCN-R50 81.2 vs 81.9 ms (profiles/r03a_schedules.txt) -- and every kernel then runs alone, as
+# bench.py times it.
+TWO_STREAM_BACKWARD = os.environ.get("DDCN_TWO_STREAM_BACKWARD", "0") == "1"
 # the mask branch's direct backward on two streams (ddcn_deform_conv_direct_backward_2s_f32): measured -0.03 ms on the
 # 3.46 ms layer, so it is opt-in
 TWO_STREAM_DIRECT = os.environ.get("DDCN_TWO_STREAM_DIRECT", "0") == "1"
+# 16-bit backward: grad_weight's chain (16-bit im2col, grad_out gather, GEMM) on a side stream beside G2 and the scatter
+# (1.17 vs 1.23 ms on the bench layer in round 2).  DDCN_TWO_STREAM_16BIT=0: one stream.
+TWO_STREAM_16BIT = os.environ.get("DDCN_TWO_STREAM_16BIT", "1") != "0"
 _side = {}
 
 
@@ -182,7 +188,7 @@ def _backward_16bit(dtype, input, offset, mask, weight, grad_output, with_bias, 
         main = torch.cuda.current_stream(input.device)
         s = _lib.current_stream(input.device)
         gw16 = L.ddcn_deform_conv_gweight_bf16 if dtype == torch.bfloat16 else L.ddcn_deform_conv_gweight_f16
-        two = g3_16 and TWO_STREAM_BACKWARD and not torch.cuda.is_current_stream_capturing()
+        two = g3_16 and TWO_STREAM_16BIT and not torch.cuda.is_current_stream_capturing()
         if two:
             # grad_weight needs only the inputs and grad_out: its chain (16-bit im2col, grad_out gather, GEMM) runs on the
             # side stream beside G2 and the LDS-atomic-bound scatter, in a workspace of its own
@@ -576,7 +582,7 @@ class _DeformConvSigmoidFunction(Function):
             args = (_lib.ptr(input), _lib.ptr(weight), _lib.ptr(offset), _lib.ptr(grad_pre), _lib.ptr(grad_input),
                     _lib.ptr(grad_offset), _lib.ptr(grad_weight), _lib.ptr(grad_bias) if ctx.with_bias else None,
                     _lib.ptr(ws), ws_bytes, g, _lib.current_stream(input.device))
-            if (TWO_STREAM_DIRECT and TWO_STREAM_BACKWARD and cd == torch.float32
+            if (TWO_STREAM_DIRECT and cd == torch.float32
                     and not torch.cuda.is_current_stream_capturing()):
                 # the weight-gradient kernel on the side stream beside the scatter (independent halves of the backward)
                 side, fork, join = _side_stream(input.device)
