@@ -1,12 +1,26 @@
 """DANet head and segmentor: `detseg/models/seg_heads/danet_head.py` (D below), `seg_heads/seg_head.py`,
 `segmentors/DANet.py` and the train / test forwards of `segmentors/single_stage.py:49-98`."""
+import os
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
 
 class PAM_Module(nn.Module):
-    """Position attention (D:72-108): softmax(Q^T K) over all pixel pairs, out = gamma * V A^T + x."""
+    """Position attention (D:72-108): softmax(Q^T K) over all pixel pairs, out = gamma * V A^T + x.
+
+    The reference materialises the whole [hw, hw] attention map (354 MB per image in fp32 at 97 x 97, 2.8 GB for a batch
+    of 8, several times over with softmax's input, output and their gradients).  A softmax row belongs to ONE query
+    pixel, so the map can be computed in blocks of query pixels -- softmax(Q_blk^T K), then V A_blk^T -- with the same
+    arithmetic per element; `max_map_elems` bounds batch x block x hw.  Measured on MI355X (profiles/r03a_pam_blocks.txt):
+    blocks cost 1 % of the fp32 DDCN-R101 step (464.3 -> 468.5 ms) and 10 % of the bf16 inference step, and take 7.4 GB off
+    the R101 peak -- so the default is the reference's single map (None), and blocks of at most 2^27 elements are used only
+    under torch.autocast when the map is larger than anything this build has run there (the one full-size R101 autocast
+    run faulted inside PyTorch's / rocBLAS's kernels on the 8 x 9409 x 9409 map)."""
+
+    max_map_elems = int(os.environ.get("DDCN_PAM_MAX_MAP_ELEMS", 0)) or None
+    autocast_map_elems = 1 << 27
 
     def __init__(self, in_dim):
         super().__init__()
@@ -18,12 +32,24 @@ class PAM_Module(nn.Module):
 
     def forward(self, x):
         b, c, h, w = x.shape
+        hw = h * w
         q = self.query_conv(x).flatten(2).transpose(1, 2)        # [b, hw, c/8]
         k = self.key_conv(x).flatten(2)                          # [b, c/8, hw]
-        attention = torch.softmax(torch.bmm(q, k), dim=-1)       # [b, hw, hw]
         v = self.value_conv(x).flatten(2)                        # [b, c, hw]
-        out = torch.bmm(v, attention.transpose(1, 2)).view(b, c, h, w)
-        return self.gamma * out + x
+        limit = self.max_map_elems
+        if limit is None and torch.is_autocast_enabled("cuda") and x.is_cuda and b * hw * hw > 2 * self.autocast_map_elems:
+            limit = self.autocast_map_elems
+        blk = hw if not limit else max(1, min(hw, limit // max(1, b * hw)))
+        if blk >= hw:
+            attention = torch.softmax(torch.bmm(q, k), dim=-1)   # [b, hw, hw]
+            out = torch.bmm(v, attention.transpose(1, 2))
+        else:
+            outs = []
+            for s in range(0, hw, blk):
+                a = torch.softmax(torch.bmm(q[:, s:s + blk], k), dim=-1)        # [b, blk, hw]: rows of the full map
+                outs.append(torch.bmm(v, a.transpose(1, 2)))                    # [b, c, blk]
+            out = torch.cat(outs, dim=2)
+        return self.gamma * out.view(b, c, h, w) + x
 
 
 class CAM_Module(nn.Module):

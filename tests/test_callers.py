@@ -351,3 +351,24 @@ def test_overlapped_reducer_world4_uneven_buckets_and_rank_dependent_unused_para
     for r in res:
         for n in exp:
             assert torch.allclose(torch.from_numpy(r[3][n]), exp[n], rtol=1e-5, atol=1e-5), (r[0], n)
+
+
+def test_pam_query_blocks_equal_the_single_attention_map():
+    """PAM in blocks of query pixels (callers/danet.py) against the reference's single [hw, hw] map
+    (detseg/models/seg_heads/danet_head.py:83-104): same output and gradients."""
+    torch.manual_seed(2)
+    pam = callers.PAM_Module(16)
+    with torch.no_grad():
+        pam.gamma.fill_(0.7)
+    x = torch.randn(2, 16, 9, 11)
+    res = []
+    for limit in (None, 2 * 99 * 20, 2 * 99):               # one block; blocks of 20 query pixels; one pixel per block
+        pam.max_map_elems = limit
+        pam.zero_grad(set_to_none=True)
+        xi = x.clone().requires_grad_(True)
+        out = pam(xi)
+        out.square().sum().backward()
+        res.append([out.detach(), xi.grad, pam.query_conv.weight.grad.clone(), pam.value_conv.weight.grad.clone()])
+    for other in res[1:]:
+        for a, b in zip(res[0], other):
+            assert torch.allclose(a, b, rtol=1e-5, atol=1e-6)
