@@ -466,11 +466,20 @@ def main():
                     help="model workloads: forward and loss under torch.autocast(bfloat16) -- fp32 parameters, 16-bit "
                          "activations, the DDCN layers on their native 16-bit forward / backward.  An extra figure: the "
                          "reference trains in fp32 and the BASELINE workloads are quoted in fp32 (the default)")
+    ap.add_argument("--force-amp-r101", action="store_true",
+                    help="run --workload r101 --amp bf16 at full size although that combination has faulted the GPU in "
+                         "PyTorch's / rocBLAS's bf16 kernels of the DANet head (DESIGN.md section 6); not for shared machines")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     args = ap.parse_args()
     if args.gpus < 1:
         raise SystemExit("--gpus must be >= 1")
+    if args.workload == "r101" and args.amp != "off" and not args.hw and not args.force_amp_r101:
+        raise SystemExit("bench.py: --workload r101 --amp bf16 at 769x769 batch 8 is refused: both runs of it ended in a GPU "
+                         "memory fault, the second with every DDCN call on the fp32 kernels (the fault is raised inside the "
+                         "DANet head's attention, after MIOpen's synchronous find of its last 1x1 convolution: PyTorch / "
+                         "rocBLAS bf16 kernels on the 8 x 9409 x 9409 map; DESIGN.md section 6).  The BASELINE workloads are "
+                         "fp32; --hw H W runs a reduced size, --force-amp-r101 overrides.")
 
     if os.environ.get("DDCN_BENCH_WATCHDOG"):     # debugging aid: dump every thread's stack after N seconds
         import faulthandler
