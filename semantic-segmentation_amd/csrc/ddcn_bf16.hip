@@ -381,7 +381,13 @@ __global__ __launch_bounds__(IT, (PAIR && !PIXOCT) ? 3 : 2) void im2col_bf16_til
     // vector; the 8 lanes of a group write 128 contiguous bytes.
     const int Cg = a.C / a.groups;
     u32x4 *tb = patch + 2 * a.RS + (t & ~63);                  // this wave's 64 slots
-    const long pix8 = (long)a.tiles * (IT / 8);                // pixel octets per image
+    // pixel octets of one image: the row-major grid (ho, wo / 8) -- only octets that hold a pixel of the map exist, so the
+    // contraction of G3 is Ho * ceil(Wo / 8) * 8 pixels (+7 % at 97 x 97) instead of the tiles' 256 lanes each (+41 %)
+    const int OW = (a.Wo + 7) >> 3;
+    const long pix8 = (long)a.Ho * OW;
+    auto pix_oct = [&](int tl) -> long {                       // octet of lane tl of this tile (callers: lanes inside the map)
+        return (long)(tyi * TH + tl / TW) * OW + ((txi * TW + (tl % TW)) >> 3);
+    };
     auto pixoct_row = [&](int oc, int k) -> long {             // row of channel c_begin + 8*oc (+ i) for tap k
         const int c = c_begin + oc * 8, grp = c / Cg;
         return (long)grp * a.Kg + (long)k * Cg + (c - grp * Cg);
@@ -397,11 +403,14 @@ __global__ __launch_bounds__(IT, (PAIR && !PIXOCT) ? 3 : 2) void im2col_bf16_til
         u32x4 r;
         r.x = v[0] | ((unsigned)v[1] << 16); r.y = v[2] | ((unsigned)v[3] << 16);
         r.z = v[4] | ((unsigned)v[5] << 16); r.w = v[6] | ((unsigned)v[7] << 16);
-        ((u32x4 *)a.col)[(((long)n * pix8 + (long)tile * (IT / 8) + (t >> 3)) * a.KO * 8) + pixoct_row(oc, k) + (t & 7)] = r;
+        // the lane group's first pixel decides whether the octet exists (its 8 lanes share ho and wo / 8)
+        const int gl = t & ~7;
+        if (tyi * TH + gl / TW < a.Ho && txi * TW + (gl % TW) < a.Wo)
+            ((u32x4 *)a.col)[(((long)n * pix8 + pix_oct(gl)) * a.KO * 8) + pixoct_row(oc, k) + (t & 7)] = r;
     };
     // one element of a pixel-octet column: lane tl of this tile, channel c_begin + 8*oc + e, tap k
     auto pixoct_put = [&](int oc, int k, int tl, u32x4 o) {
-        bf16_t *dst = (bf16_t *)a.col + ((((long)n * pix8 + (long)tile * (IT / 8) + (tl >> 3)) * a.KO * 8) + pixoct_row(oc, k)) * 8 + (tl & 7);
+        bf16_t *dst = (bf16_t *)a.col + ((((long)n * pix8 + pix_oct(tl)) * a.KO * 8) + pixoct_row(oc, k)) * 8 + (tl & 7);
         dst[0] = (bf16_t)o.x; dst[8] = (bf16_t)(o.x >> 16); dst[16] = (bf16_t)o.y; dst[24] = (bf16_t)(o.y >> 16);
         dst[32] = (bf16_t)o.z; dst[40] = (bf16_t)(o.z >> 16); dst[48] = (bf16_t)o.w; dst[56] = (bf16_t)(o.w >> 16);
     };
@@ -1199,9 +1208,9 @@ int launch_gemm_gcol_f16(const void *weight, const void *gout, float *gcol, void
 //   C = fp32 partial sums added into gw'[Co][tap][Cg] (atomics: images x K splits), then gw[o][c][tap] += gw'[o][tap][c].
 namespace {
 
-// one thread per 8 consecutive k (= 8 pixels of one tile row): eight 2-byte loads, one 16-byte store
+// one thread per 8 consecutive k (= one pixel octet: 8 pixels of one map row): eight 2-byte loads, one 16-byte store
 __global__ __launch_bounds__(256) void gout_pixblock_kernel(const bf16_t *gout, u32x4 *ap, long total8, int Co, int Cog,
-                                                           int KT, int tiles_w, int Ho, int Wo)
+                                                           int KT, int Ho, int Wo)
 {
     const long i = (long)blockIdx.x * 256 + threadIdx.x;
     if (i >= total8) return;
@@ -1212,8 +1221,9 @@ __global__ __launch_bounds__(256) void gout_pixblock_kernel(const bf16_t *gout, 
     const int groups = Co / Cog;
     const int grp = (int)(rest % groups);
     const long n = rest / groups;
-    const int idx = kt * 32 + k8 * 8, tile = idx >> 8, t = idx & 255;
-    const int ho = (tile / tiles_w) * TH + (t >> 5), wo0 = (tile % tiles_w) * TW + (t & 31);
+    const int OW = (Wo + 7) >> 3;
+    const int oct = kt * 4 + k8;                      // pixel octet (ho, wo / 8); beyond the map: zeros
+    const int ho = oct / OW, wo0 = (oct - ho * OW) * 8;
     const bf16_t *src = gout + ((n * Co + (long)grp * Cog + o) * Ho + min(ho, Ho - 1)) * Wo;
     unsigned short v[8];
 #pragma unroll
@@ -1242,15 +1252,17 @@ __global__ __launch_bounds__(256) void gweight_finish_kernel(const float *gwp, f
     gw[i] += gwp[(o * 9 + tap) * Cg + c];
 }
 
-struct Gw16Plan { size_t b_bytes, a_bytes, p_bytes; long kpix; };
+// kpix: pixels of one image in the contraction (whole octets); kpad: the same rounded up to whole 32-k tiles (the A operand
+// is zero-padded to it, the B operand's tail is cut by its descriptor)
+struct Gw16Plan { size_t b_bytes, a_bytes, p_bytes; long kpix, kpad; };
 
 Gw16Plan gw16_plan(const ddcn_geom &g)
 {
     Gw16Plan pl;
-    const long tiles = (long)((g.Wo + TW - 1) / TW) * ((g.Ho + TH - 1) / TH);
-    pl.kpix = tiles * IT;
+    pl.kpix = (long)g.Ho * ((g.Wo + 7) / 8) * 8;
+    pl.kpad = (pl.kpix + 31) / 32 * 32;
     pl.b_bytes = round_up((size_t)g.N * pl.kpix * g.C * 9 * 2, 256);
-    pl.a_bytes = round_up((size_t)g.N * pl.kpix * g.Co * 2, 256);
+    pl.a_bytes = round_up((size_t)g.N * pl.kpad * g.Co * 2, 256);
     pl.p_bytes = round_up((size_t)g.Co * (g.C / g.groups) * 9 * 4, 256);
     return pl;
 }
@@ -1264,7 +1276,7 @@ int gweight16_supported(const ddcn_geom &g)
     const long Cog = g.Co / g.groups, Kg = (long)(g.C / g.groups) * 9;
     if (Cog % 8) return fail(DDCN_ERR_UNSUPPORTED, "16-bit G3: Co/groups must be a multiple of 8 (Co=%d groups=%d)", g.Co, g.groups);
     // 31-bit byte offsets inside one image's B slab and one (image, group) A slab
-    if (pl.kpix / 8 * (long)g.C * 9 * 16 >= (1L << 31) || pl.kpix * Cog * 2 >= (1L << 31) || Kg >= (1L << 27))
+    if (pl.kpix / 8 * (long)g.C * 9 * 16 >= (1L << 31) || pl.kpad * Cog * 2 >= (1L << 31) || Kg >= (1L << 27))
         return fail(DDCN_ERR_UNSUPPORTED, "16-bit G3: tensor too large");
     Bf16Args a = {};
     a.pixoct = 1;
@@ -1307,10 +1319,10 @@ static int gweight_16(const void *x, const void *offset, const void *mask, const
         if (int rc = check_launch("im2col_16_pixoct")) return rc;
     }
     // A: grad_out in the same pixel order, blocked; the partial result starts at zero
-    const int KT = (int)(pl.kpix / 32);
-    const long atotal = (long)g.N * g.Co * pl.kpix;
+    const int KT = (int)(pl.kpad / 32);
+    const long atotal = (long)g.N * g.Co * pl.kpad;
     hipLaunchKernelGGL(gout_pixblock_kernel, dim3((unsigned)((atotal / 8 + 255) / 256)), dim3(256), 0, stream,
-                       (const bf16_t *)gout, (u32x4 *)ap, atotal / 8, g.Co, Cog, KT, a.tiles_w, g.Ho, g.Wo);
+                       (const bf16_t *)gout, (u32x4 *)ap, atotal / 8, g.Co, Cog, KT, g.Ho, g.Wo);
     const long wtotal = (long)g.Co * Kg;
     hipLaunchKernelGGL(zero_f32_kernel, dim3((unsigned)((wtotal + 255) / 256)), dim3(256), 0, stream, gwp, wtotal);
     if (int rc = check_launch("gout_pixblock")) return rc;
@@ -1320,8 +1332,8 @@ static int gweight_16(const void *x, const void *offset, const void *mask, const
     b.N = g.N; b.groups = g.groups;
     b.P = Kg;                      // columns of the product: the rows of one group's columns
     b.Cog = Cog; b.Co = g.Co;      // rows: the group's output channels
-    b.Kg = (int)pl.kpix;           // contraction: the pixels of one image
-    b.sA_img = (long)g.Co * pl.kpix; b.sA_grp = (long)Cog * pl.kpix;
+    b.Kg = (int)pl.kpix;           // contraction: the pixels of one image (whole octets; the last 32-k tile may be partial)
+    b.sA_img = (long)g.Co * pl.kpad; b.sA_grp = (long)Cog * pl.kpad;
     b.ldb = g.C * 9;
     b.sB_img = (pl.kpix / 8) * (long)b.ldb; b.sB_grp = Kg;
     // K splits: enough workgroups for the chip
