@@ -474,6 +474,7 @@ int launch_gemm_gweight(const float *gout, const float *col, float *gw, const dd
     a.nz1 = g.groups;
     const long tiles_mn = (long)((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN) * g.groups * g.N;
     int ksplit = (int)((1024 + tiles_mn - 1) / tiles_mn);
+    if (const char *e = getenv("DDCN_GEMM_GW_KSPLIT")) ksplit = atoi(e);     // experiment
     const int ktiles = (d.P + BK - 1) / BK;
     if (ksplit > ktiles) ksplit = ktiles;
     if (ksplit < 1) ksplit = 1;

@@ -174,7 +174,7 @@ def _backward_16bit(dtype, input, offset, mask, weight, grad_output, with_bias, 
     gout32 = grad_output.float() if (with_bias or not g3_16) else None
     mask32 = None if mask is None else mask.float()
     acts = [x32, off32] + ([mask32] if mask is not None else [])
-    grads = _zeros_flat(acts)
+    grads, grads_flat = _zeros_flat(acts, with_flat=True)
     gx, goff = grads[0], grads[1]
     gmask = grads[2] if mask is not None else None
     gw = torch.zeros(weight.shape, dtype=torch.float32, device=input.device)
@@ -215,8 +215,10 @@ def _backward_16bit(dtype, input, offset, mask, weight, grad_output, with_bias, 
             _lib.check(L.ddcn_gemm_gweight_f32(p(gout32), p(ws), p(gw), g, s))
         if with_bias:
             _lib.check(L.ddcn_bias_grad_f32(p(gout32), p(gb), g, s))
+    # the activation gradients share one flat fp32 buffer: one conversion kernel for the three of them
+    g16 = _flat_views(grads_flat.to(dtype), acts)
     cv = lambda t: None if t is None else t.to(dtype)
-    return cv(gx), cv(goff), cv(gmask), cv(gw), cv(gb)
+    return g16[0], g16[1], (g16[2] if mask is not None else None), cv(gw), cv(gb)
 
 
 def _bf16_forward(input, offset, mask, weight, bias, g):
@@ -244,14 +246,20 @@ def _workspace(input, g, cd=torch.float32):
     return torch.empty(nbytes // 4, dtype=torch.float32, device=input.device), nbytes
 
 
-def _zeros_flat(tensors):
-    sizes = [(t.numel() + 3) // 4 * 4 for t in tensors]
-    flat = torch.zeros(sum(sizes), dtype=tensors[0].dtype, device=tensors[0].device)
+def _flat_views(flat, tensors):
+    """Views of `flat` shaped like `tensors`, each starting on a multiple of 8 elements (16 bytes for 16-bit elements)."""
     out, o = [], 0
-    for t, n in zip(tensors, sizes):
+    for t in tensors:
         out.append(flat[o:o + t.numel()].view(t.shape))
-        o += n
+        o += (t.numel() + 7) // 8 * 8
     return out
+
+
+def _zeros_flat(tensors, dtype=None, with_flat=False):
+    total = sum((t.numel() + 7) // 8 * 8 for t in tensors)
+    flat = torch.zeros(total, dtype=dtype or tensors[0].dtype, device=tensors[0].device)
+    views = _flat_views(flat, tensors)
+    return (views, flat) if with_flat else views
 
 
 def _zeros_like_all(*tensors):
