@@ -293,9 +293,7 @@ def model_workload(args, world, rank, dev):
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     if world > 1:
-        tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dt = float(tmax.item())
+        dt = max_over_ranks(dt, dev)
     devices = job_devices(dev, world)
     grad_bytes = sum(p.numel() * p.element_size() for p in model.parameters() if p.requires_grad)
     probe = allreduce_probe(dev, world, grad_bytes, iters=5) if world > 1 else None
@@ -383,9 +381,7 @@ def inference_workload(args, world, rank, dev):
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
     if world > 1:
-        tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dt = float(tmax.item())
+        dt = max_over_ranks(dt, dev)
     if rank == 0:
         n_dcn = sum(1 for m in model.modules() if type(m).__name__ == "ModulatedDeformConvPack")
         print(json.dumps({
@@ -400,6 +396,17 @@ def inference_workload(args, world, rank, dev):
             "output_shape": list(out.shape), "finite": bool(torch.isfinite(out.float()).all()),
             "peak_mem_GB": round(torch.cuda.max_memory_allocated() / 2 ** 30, 2),
         }), flush=True)
+
+
+def max_over_ranks(value, dev):
+    """MAX of a python float over the job's ranks.  Under RCCL the scalar lives on the GPU (the backend has no CPU path);
+    under gloo -- the rehearsal with several ranks on ONE GPU -- it stays on the host: a GPU tensor handed to gloo while
+    this process still has work queued on the shared device is the deadlock dist_utils.drain_for_host_backend describes
+    (it hung the rehearsal once the per-bucket probes made such calls frequent)."""
+    on_gpu = dist.get_backend() != "gloo"
+    t = torch.tensor([value], device=dev if on_gpu else "cpu", dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
 
 
 def allreduce_probe(dev, world, nbytes, iters=10):
@@ -419,9 +426,7 @@ def allreduce_probe(dev, world, nbytes, iters=10):
         dist.all_reduce(buf)
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / iters
-    t = torch.tensor([dt], device=dev, dtype=torch.float64)
-    dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    dt = float(t.item())
+    dt = max_over_ranks(dt, dev)
     return dict(bytes=nbytes, ms=round(dt * 1e3, 4), bus_GBps=round(2 * (world - 1) / world * nbytes / dt / 1e9, 2))
 
 
@@ -551,9 +556,7 @@ def main():
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     if world > 1:
-        tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dt = float(tmax.item())
+        dt = max_over_ranks(dt, dev)
 
     # the same step under the OTHER backward schedule (one stream <-> weight-gradient GEMM on a side stream beside the
     # scatter), so that the line shows what the default buys; per-kernel rooflines below are timed one kernel at a time,

@@ -44,6 +44,8 @@ struct GemmArgs {
     int nb, nn;               // column tiles per slice: nb of width BN, then nn of width BN_TAIL
     int total_big, total_nar;    // tiles_m * nb * nz wide tiles, tiles_m * nn * nz narrow tiles
     int blocks_big, blocks_nar;  // workgroups per class: two tiles (one per wave group) each
+    // persistent schedule (gemm_f32_sk): G wave groups, T output tiles of S K-steps each (kimgs images folded into K)
+    int sk_G, sk_T, sk_S, sk_ktiles, sk_kimgs, sk_R, sk_tiles_n, sk_utail;
 };
 
 // Descriptor over [base, base + elems_left) floats, clamped to [0, 2 GiB).  32-bit scalar compares only: a 64-bit
@@ -369,6 +371,256 @@ __global__ __launch_bounds__(2 * NT) void gemm_f32_mfma(GemmArgs a)
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// Persistent variant: one workgroup per CU for the whole launch, every wave group walks a list of SEGMENTS -- (output
+// tile, range of K steps) -- through ONE uninterrupted LDS pipeline: the loads of a segment's first K steps are issued
+// during the last steps of the segment before it, and a segment's epilogue runs in the memory phase that follows its
+// last compute phase, i.e. while the OTHER group of the workgroup streams its MFMAs.  What that removes from
+// gemm_f32_mfma: the exposed prologue (first loads of a tile) and epilogue of every tile and the gap between two
+// workgroups on a CU (one workgroup fits) -- together about 3 K steps per tile, measured as efficiency = steps /
+// (steps + 3) on G2 (K = 512: 84 %, 256: 73 %, 128: 57 % of the MFMA peak).
+// Schedule ("data-parallel rounds + stream-K tail"): with G groups and T tiles of S steps, every group takes R = T / G
+// whole tiles (tile = r * G + slot: the tiles in flight at any time are neighbours in the logical order, as in the flat
+// grid); the T - R * G tiles left are
+//   ATOMIC (G3: the output is accumulated with atomics anyway): cut into G equal runs of steps, wherever they fall
+//          inside a tile (stream-K): every group ends within one step of the others;
+//   else   handed out whole (results stay bit-reproducible: plain stores, one writer per element).
+// For G3 the images are folded into K (S = images x K tiles): one output tile is one (m, n) block of grad_weight.
+constexpr int SK_MAXSEG = 64;          // segments per group the LDS table holds (whole tiles + stream-K pieces)
+constexpr int SK_ENTRY = 12;           // dwords per table entry
+
+__device__ __forceinline__ int sk_bound(const GemmArgs &a, int g, bool atomic)
+{
+    if (g <= 0) return 0;
+    if (g >= a.sk_G) return a.sk_utail;
+    if (!atomic) {
+        const int trem = a.sk_utail / a.sk_S;
+        return (int)((long)g * trem / a.sk_G) * a.sk_S;
+    }
+    int b = (int)((long)g * a.sk_utail / a.sk_G);
+    const int r = b % a.sk_S;            // a run that would start / end one step away from a tile boundary is snapped onto it
+    if (r == 1) b -= 1;
+    else if (r == a.sk_S - 1) b += 1;
+    return b;
+}
+
+template <bool A_KC, bool B_KC, bool ATOMIC>
+__global__ __launch_bounds__(2 * NT) void gemm_f32_sk(GemmArgs a)
+{
+    typedef typename LoaderSel<A_KC, BM>::type LA;
+    typedef typename LoaderSel<B_KC, BN>::type LB;
+    constexpr int LDA = LA::LD, LDB = LB::LD;
+    constexpr int WN_ = 64, WAVES_N = 2, WM_ = 64, MI = 2, NJ = 2;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int grp = __builtin_amdgcn_readfirstlane(threadIdx.x >> 8);
+    float *As = smem + grp * (BK * LDA + BK * LDB), *Bs = As + BK * LDA;
+    int *table = reinterpret_cast<int *>(smem + 2 * (BK * LDA + BK * LDB)) + grp * (SK_MAXSEG * SK_ENTRY);
+    const int t = threadIdx.x & (NT - 1);
+    const int lane = t & 63, wave = t >> 6;
+    const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+    const int wg = __builtin_amdgcn_readfirstlane(xcd_order(blockIdx.x, gridDim.x));
+    const int g = 2 * wg + grp;
+    const bool fold = a.sk_kimgs > 1;
+
+    // tail runs of this group and of its partner: both execute the larger step count (barriers are per workgroup)
+    const int b0 = __builtin_amdgcn_readfirstlane(sk_bound(a, 2 * wg, ATOMIC));
+    const int b1 = __builtin_amdgcn_readfirstlane(sk_bound(a, 2 * wg + 1, ATOMIC));
+    const int b2 = __builtin_amdgcn_readfirstlane(sk_bound(a, 2 * wg + 2, ATOMIC));
+    const int nsteps = a.sk_R * a.sk_S + max(b1 - b0, b2 - b1);
+    const int tb = grp ? b1 : b0, te = grp ? b2 : b1;          // this group's run of tail steps
+    const int tfirst = tb / a.sk_S;
+    const int nseg = a.sk_R + (te > tb ? (te + a.sk_S - 1) / a.sk_S - tfirst : 0);
+
+    // Segment table, one entry per lane (all the integer divisions of the schedule happen here, in parallel, not in the K
+    // loop): {m0, n0, kt, len, offA lo/hi, offB lo/hi, offC lo/hi} -- element offsets of the segment's first step.
+    if (t < nseg) {
+        int tile, kb, len;
+        if (t < a.sk_R) {
+            tile = t * a.sk_G + g; kb = 0; len = a.sk_S;
+        } else {
+            const int q = t - a.sk_R;
+            const int start = q == 0 ? tb : (tfirst + q) * a.sk_S;
+            const int end = min((tfirst + q + 1) * a.sk_S, te);
+            tile = a.sk_R * a.sk_G + tfirst + q; kb = start - (tfirst + q) * a.sk_S; len = end - start;
+        }
+        const int per_z = a.tiles_m * a.sk_tiles_n;
+        const int z = tile / per_z, rem = tile - z * per_z;
+        int tm, tn;
+        band_order(rem, a.tiles_m, a.sk_tiles_n, tm, tn);
+        const int z1 = z % a.nz1, z0 = z / a.nz1;              // folded images: z = weight group, the image comes from kb
+        const int img = kb / a.sk_ktiles, kt = kb - img * a.sk_ktiles;
+        const long zi = fold ? img : z0;
+        const long offA = zi * a.sA0 + z1 * a.sA1, offB = zi * a.sB0 + z1 * a.sB1;
+        const long offC = (fold ? 0 : z0 * a.sC0) + z1 * a.sC1;
+        int *e = table + t * SK_ENTRY;
+        e[0] = tm * BM; e[1] = tn * BN; e[2] = kt; e[3] = len;
+        e[4] = (int)offA; e[5] = (int)(offA >> 32); e[6] = (int)offB; e[7] = (int)(offB >> 32);
+        e[8] = (int)offC; e[9] = (int)(offC >> 32); e[10] = 0; e[11] = 0;
+    }
+    __syncthreads();
+
+    // cursors: plain scalars (SGPRs) refilled from the table at a segment change
+    struct Cur { int idx, left, m0, n0, kt; long offA, offB, offC; };
+    auto fetch = [&](Cur &c) {
+        if (c.idx < nseg) {
+            const int *e = table + c.idx * SK_ENTRY;
+            c.m0 = __builtin_amdgcn_readfirstlane(e[0]); c.n0 = __builtin_amdgcn_readfirstlane(e[1]);
+            c.kt = __builtin_amdgcn_readfirstlane(e[2]); c.left = __builtin_amdgcn_readfirstlane(e[3]);
+            const unsigned al = __builtin_amdgcn_readfirstlane(e[4]), ah = __builtin_amdgcn_readfirstlane(e[5]);
+            const unsigned bl = __builtin_amdgcn_readfirstlane(e[6]), bh = __builtin_amdgcn_readfirstlane(e[7]);
+            const unsigned cl = __builtin_amdgcn_readfirstlane(e[8]), ch = __builtin_amdgcn_readfirstlane(e[9]);
+            c.offA = (long)(((unsigned long)ah << 32) | al);
+            c.offB = (long)(((unsigned long)bh << 32) | bl);
+            c.offC = (long)(((unsigned long)ch << 32) | cl);
+        } else {
+            c.left = 0;
+        }
+        ++c.idx;
+    };
+    Cur lc{}, cc{};                    // load cursor (two steps ahead of the compute cursor)
+    fetch(lc);
+    fetch(cc);
+
+    f32x16 acc[MI][NJ];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    LA la; LB lb;
+    la.init(As, a.lda, t);
+    lb.init(Bs, a.ldb, t);
+    f32x4 ra[LA::NV], rb[LB::NV];
+
+    // issue the loads of the load cursor's step (an exhausted cursor reads zeros through empty descriptors), then advance it
+    auto gload = [&]() -> int {
+        const bool live = lc.left > 0;
+        const int k0 = lc.kt * BK;
+        const int kvalid = live ? max(a.K - k0, 0) : 0;
+        const long oa = LA::origin(a.lda, lc.m0, k0), ob = LB::origin(a.ldb, lc.n0, k0);
+        const long nA = live ? a.nA : 0, nB = live ? a.nB : 0;
+        la.load(make_rsrc(a.A + lc.offA + oa, LA::extent(a.lda, nA - oa, kvalid, lc.m0)), ra);
+        lb.load(make_rsrc(a.B + lc.offB + ob, LB::extent(a.ldb, nB - ob, kvalid, lc.n0)), rb);
+        if (live) {
+            if (--lc.left == 0) {
+                fetch(lc);
+            } else if (++lc.kt == a.sk_ktiles) {     // folded images: on to the next image's slice
+                lc.kt = 0; lc.offA += a.sA0; lc.offB += a.sB0;
+            }
+        }
+        return kvalid;
+    };
+    auto sstore = [&](int kvalid) {
+        la.store(ra, kvalid);
+        lb.store(rb, kvalid);
+    };
+
+    int kv = gload();
+    sstore(kv);
+    kv = gload();
+    __syncthreads();
+    if (grp == 1) __syncthreads();
+
+    const int li = lane & 31, lh = lane >> 5;
+    const unsigned lane_off = (unsigned)(((long)(wm * WM_ + 4 * lh) * a.ldc + wn * WN_ + li) * 4);
+    bool clear_acc = false;
+    for (int step = 0; step < nsteps; ++step) {
+        __builtin_amdgcn_s_setprio(2);
+        if (clear_acc) {           // first step of a new segment (uniform): the stores of the last one were issued a phase ago
+            const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) acc[i][j] = zero16;
+            clear_acc = false;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        const float *as = As + wm * WM_ + li;
+        const float *bs = Bs + wn * WN_ + li;
+        constexpr int PF = 2, KS = BK / 2;
+        float av[PF + 1][MI], bv[PF + 1][NJ];
+#pragma unroll
+        for (int s0 = 0; s0 < PF; ++s0) {
+#pragma unroll
+            for (int i = 0; i < MI; ++i) av[s0][i] = as[(2 * s0 + lh) * LDA + 32 * i];
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) bv[s0][j] = bs[(2 * s0 + lh) * LDB + 32 * j];
+        }
+#pragma unroll
+        for (int kk = 0; kk < KS; ++kk) {
+            const int c = kk % (PF + 1), nx = (kk + PF) % (PF + 1);
+            if (kk + PF < KS) {
+                const int k = 2 * (kk + PF) + lh;
+#pragma unroll
+                for (int i = 0; i < MI; ++i) av[nx][i] = as[k * LDA + 32 * i];
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) bv[nx][j] = bs[k * LDB + 32 * j];
+            }
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int j = 0; j < NJ; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[c][i], bv[c][j], acc[i][j], 0, 0, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, MI + NJ, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, MI * NJ, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_setprio(0);
+        __syncthreads();   // this group's step is consumed; the other group starts computing
+        sstore(kv);
+        __builtin_amdgcn_sched_barrier(0);
+        kv = gload();
+        __builtin_amdgcn_sched_barrier(0);
+        // The segment's last step has just been computed: write it out under the other group's compute phase.  That
+        // phase streams MFMAs at raised priority, and a wave's VALU instructions barely issue beside it (measured: x10),
+        // so the epilogue of an interior tile is VALU-free: the lane's offset is tile-independent, the (i, j, e) part a
+        // scalar offset, the accumulators are cleared at the start of this group's own next compute phase.  Edge tiles
+        // (last row / column of tiles) mask per element.
+        if (cc.left > 0 && --cc.left == 0) {
+            const long o = (long)cc.m0 * a.ldc + cc.n0;
+            const __amdgpu_buffer_rsrc_t rc = make_rsrc(a.C + cc.offC + o, a.nC - o);
+            const bool interior = cc.m0 + BM <= a.M && cc.n0 + BN <= a.N;
+            if (interior) {
+#pragma unroll
+                for (int i = 0; i < MI; ++i)
+#pragma unroll
+                    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+                        for (int e = 0; e < 16; ++e) {
+                            const int mr = i * 32 + (e & 3) + 8 * (e >> 2);
+                            const unsigned soff = (unsigned)(((long)mr * a.ldc + j * 32) * 4);
+                            const float v = acc[i][j][e];
+                            if (ATOMIC) __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(v, rc, lane_off, soff, 0);
+                            else __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rc, lane_off, soff, 0);
+                        }
+            } else {
+#pragma unroll
+                for (int i = 0; i < MI; ++i)
+#pragma unroll
+                    for (int j = 0; j < NJ; ++j) {
+                        const int nl = wn * WN_ + j * 32 + li;
+#pragma unroll
+                        for (int e = 0; e < 16; ++e) {
+                            const int ml = wm * WM_ + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+                            const bool ok = (cc.m0 + ml < a.M) && (cc.n0 + nl < a.N);
+                            const unsigned voff = ok ? (unsigned)(((long)ml * a.ldc + nl) * 4) : OOB;
+                            const float v = acc[i][j][e];
+                            if (ATOMIC) __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(v, rc, voff, 0, 0);
+                            else __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rc, voff, 0, 0);
+                        }
+                    }
+            }
+            clear_acc = true;
+            fetch(cc);
+        }
+        __syncthreads();   // the next step is in place; the other group starts its memory phase
+    }
+    if (grp == 0) __syncthreads();
+}
+
 static int device_slots()
 {
     // tiles in flight on the current device: one two-group workgroup per CU
@@ -423,6 +675,54 @@ static int launch(GemmArgs &a, int nz0, hipStream_t stream, const char *what)
     return check_launch(what);
 }
 
+
+constexpr int SK_NOT_APPLICABLE = -1000;   // internal: the caller falls back to the flat grid
+
+// Persistent launch (see gemm_f32_sk).  fold_images: the nz0 images are part of the contraction (G3).
+template <bool A_KC, bool B_KC, bool ATOMIC>
+static int launch_sk(GemmArgs &a, int nz0, bool fold_images, hipStream_t stream, const char *what)
+{
+    constexpr int LDA = LoaderSel<A_KC, BM>::type::LD;
+    constexpr int LDB = LoaderSel<B_KC, BN>::type::LD;
+    const size_t smem = (size_t)(2 * BK * LDA + 2 * BK * LDB) * sizeof(float) + 2 * SK_MAXSEG * SK_ENTRY * sizeof(int);
+    if (a.lda >= (1L << 21) || a.ldb >= (1L << 21) || a.ldc >= (1L << 21))
+        return fail(DDCN_ERR_UNSUPPORTED, "%s: leading dimension beyond 2^21 elements", what);
+    static std::atomic<uint64_t> raised{0};
+    if (!raise_lds_limit(reinterpret_cast<const void *>(&gemm_f32_sk<A_KC, B_KC, ATOMIC>), (int)smem, raised))
+        return fail(DDCN_ERR_LAUNCH, "%s: cannot raise the dynamic LDS limit to %zu bytes", what, smem);
+    a.tiles_m = (a.M + BM - 1) / BM;
+    const long tiles_n = (a.N + BN - 1) / BN;
+    const long nzo = (fold_images ? 1 : (long)nz0) * a.nz1;
+    const long T = a.tiles_m * tiles_n * nzo;
+    const long ktiles = (a.K + BK - 1) / BK;
+    const long S = ktiles * (fold_images ? nz0 : 1);
+    if (T == 0 || S == 0) return DDCN_OK;
+    const long G = device_slots();
+    const long R = T / G;
+    const long utail = (T - R * G) * S;
+    if (T > 0x3fffffffL || utail > 0x3fffffffL || S < 4) return fail(DDCN_ERR_UNSUPPORTED, "%s: schedule out of range", what);
+    // segments per group: R whole tiles + the pieces of its tail run; the LDS table holds SK_MAXSEG
+    if (R + (utail / G + S - 1) / S + 3 > SK_MAXSEG) return SK_NOT_APPLICABLE;
+    a.sk_G = (int)G; a.sk_T = (int)T; a.sk_S = (int)S; a.sk_ktiles = (int)ktiles; a.sk_kimgs = fold_images ? nz0 : 1;
+    a.sk_R = (int)R; a.sk_tiles_n = (int)tiles_n; a.sk_utail = (int)utail;
+    hipLaunchKernelGGL((gemm_f32_sk<A_KC, B_KC, ATOMIC>), dim3((unsigned)(G / 2)), dim3(2 * NT), smem, stream, a);
+    return check_launch(what);
+}
+
+// DDCN_GEMM_SK: 0 = flat grid everywhere (gemm_f32_mfma), 1 = persistent kernel wherever it is built (G2, G3), unset = where it
+// was measured faster (profiles/r03b_gemm_persistent.txt): G2 with a short contraction (Co / groups <= 256: the flat grid
+// pays ~3 K steps of prologue / epilogue / dispatch per tile, 8 steps long there: 73 % -> 80 % of the MFMA peak at the R101
+// layer3 shape, 55 % -> 61 % at layer2's).  Not for long contractions: the statically partitioned persistent grid ends with its
+// slowest CU and its stream-K runs share no operand tiles in L2 (G3 at config 1: 0.76 vs 0.70 ms).
+static bool use_sk(long tiles, long steps_per_tile, bool g3)
+{
+    const char *e = getenv("DDCN_GEMM_SK");          // read per call: tests switch it
+    const int env = e ? atoi(e) : -1;
+    if (env >= 0) return env != 0 && steps_per_tile >= 4;
+    if (g3) return false;
+    return steps_per_tile >= 4 && steps_per_tile <= 8 && tiles * steps_per_tile >= 8L * device_slots();
+}
+
 // G1: out[n][g] (Cog x P) = W[g] (Cog x Kg, k contiguous) * col[n][g] (Kg x ld) (+ bias)
 int launch_gemm_out(const float *weight, const float *col, const float *bias, float *out, const ddcn_geom &g,
                     hipStream_t stream)
@@ -455,6 +755,11 @@ int launch_gemm_gcol(const float *weight, const float *gout, float *gcol, const 
     a.nz1 = g.groups; a.ksplit = 1; a.kchunk = (int)round_up(d.Cog, BK);
     static const int env_nt = getenv("DDCN_GEMM_NT") ? atoi(getenv("DDCN_GEMM_NT")) : 0;
     a.stream_out = env_nt;    // opt-in: measured slower (0.704 vs 0.692 ms), see DDCN_IM2COL_STORE_AUX
+    const long tiles = (long)((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN) * g.groups * g.N;
+    if (!env_nt && use_sk(tiles, (a.K + BK - 1) / BK, false)) {
+        const int rc = launch_sk<false, false, false>(a, g.N, false, stream, "gemm_gcol");
+        if (rc != SK_NOT_APPLICABLE) return rc;
+    }
     return launch<false, false, false>(a, g.N, stream, "gemm_gcol");
 }
 
@@ -472,10 +777,29 @@ int launch_gemm_gweight(const float *gout, const float *col, float *gw, const dd
     a.sC0 = 0; a.sC1 = (long)d.Cog * d.Kg;
     a.nA = a.sA1; a.nB = a.sB1; a.nC = a.sC1;
     a.nz1 = g.groups;
+    const long tiles_out = (long)((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN) * g.groups;
+    if (use_sk(tiles_out, (long)((a.K + BK - 1) / BK) * g.N, true)) {
+        const int rc = launch_sk<true, true, true>(a, g.N, true, stream, "gemm_gweight");
+        if (rc != SK_NOT_APPLICABLE) return rc;
+    }
+    // Split-K factor from a cost model of the flat grid (in K steps; fitted on profiles/r03b_gw_ksplit.txt, where it ranks
+    // the twelve factors tried at config 1 in their measured order): whole rounds of wide tiles cost their K loop plus ~3
+    // steps of prologue / epilogue / dispatch; the tiles of the last, partial round run as quarter-width tiles, four
+    // times as many, whose steps cost ~0.4 of a wide one (launch() below); less than one round stays wide.
     const long tiles_mn = (long)((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN) * g.groups * g.N;
-    int ksplit = (int)((1024 + tiles_mn - 1) / tiles_mn);
-    if (const char *e = getenv("DDCN_GEMM_GW_KSPLIT")) ksplit = atoi(e);     // experiment
     const int ktiles = (d.P + BK - 1) / BK;
+    const long slots = device_slots();
+    int ksplit = 1;
+    double best = 1e30;
+    for (int s = 1; s <= 16 && s <= ktiles; ++s) {
+        const double steps = (double)((ktiles + s - 1) / s);
+        const long tiles = tiles_mn * s, full = tiles / slots, rem = tiles - full * slots;
+        double cost;
+        if (full == 0) cost = steps + 3;
+        else cost = full * (steps + 3) + (rem ? (double)((4 * rem + slots - 1) / slots) * (0.4 * steps + 3) : 0.0);
+        if (cost < best - 1e-9) { best = cost; ksplit = s; }
+    }
+    if (const char *e = getenv("DDCN_GEMM_GW_KSPLIT")) ksplit = atoi(e);     // experiment
     if (ksplit > ktiles) ksplit = ktiles;
     if (ksplit < 1) ksplit = 1;
     const int tiles_per = (ktiles + ksplit - 1) / ksplit;

@@ -605,3 +605,44 @@ def test_full_size_config1_properties():
     lhs = (o.detach().double() * gd.double()).sum()
     assert abs(((wg.grad.double() * wd.double()).sum() - lhs) / lhs).item() <= 1e-4
     assert abs(((xg.grad.double() * xd.double()).sum() - lhs) / lhs).item() <= 1e-4
+
+
+# ---------------------------------------------------------------- persistent (stream-K) fp32 GEMMs
+@pytest.mark.parametrize("mode", ["1", "0"], ids=["persistent", "flat_grid"])
+@pytest.mark.parametrize("geo", [
+    dict(N=3, Ci=64, Co=160, H=40, W=45, groups=1),      # fewer tiles than wave groups: everything is tail
+    dict(N=1, Ci=128, Co=136, H=97, W=97, groups=1),     # G2: one whole round + a tail; M, N and K edges
+    dict(N=2, Ci=96, Co=320, H=33, W=61, groups=2),      # weight groups; G3 folds both images into K
+    dict(N=5, Ci=32, Co=256, H=50, W=50, groups=1),      # five images folded into K
+], ids=lambda d: "n%d_c%d_co%d_%dx%d_g%d" % (d["N"], d["Ci"], d["Co"], d["H"], d["W"], d["groups"]))
+def test_persistent_gemms_against_fp64_matmul(geo, mode, monkeypatch):
+    """G2 and G3 through the persistent kernel (gemm_f32_sk: whole rounds + stream-K tail, images folded into K for G3,
+    DDCN_GEMM_SK=1 forces it) and through the flat grid (=0), against fp64 products; G2 twice: its plain stores make
+    it bit-reproducible.  Reference call sites: deform_conv_cuda.cpp:503-506 (G2), :539-544 (G3)."""
+    monkeypatch.setenv("DDCN_GEMM_SK", mode)
+    c = cases.C("sk", N=geo["N"], Ci=geo["Ci"], Co=geo["Co"], H=geo["H"], W=geo["W"], pad=1, dil=1, groups=geo["groups"])
+    g = _geom(c)
+    L = _lib.lib()
+    G, P = geo["groups"], g.Ho * g.Wo
+    Kg, Cog = c["Ci"] // G * 9, c["Co"] // G
+    ld = L.ddcn_col_ld(g)
+    rng = np.random.default_rng(6)
+    w = rng.standard_normal((G, Cog, Kg)).astype(np.float32)
+    col = rng.standard_normal((c["N"], G, Kg, P)).astype(np.float32)
+    gout = rng.standard_normal((c["N"], G, Cog, P)).astype(np.float32)
+    col_d = torch.full((c["N"], G * Kg, ld), float("nan"), device=DEV)
+    col_d[:, :, :P] = torch.from_numpy(col.reshape(c["N"], G * Kg, P)).to(DEV)
+    w_d, gout_d = _t(w), _t(gout)
+    s = _lib.current_stream(torch.device(DEV))
+    exp = np.einsum("gok,ngop->ngkp", w.astype(np.float64), gout.astype(np.float64)).reshape(c["N"], G * Kg, P)
+    runs = []
+    for _ in range(2):
+        gcol = torch.full((c["N"], G * Kg, ld), float("nan"), device=DEV)
+        _lib.check(L.ddcn_gemm_gcol_f32(_lib.ptr(w_d), _lib.ptr(gout_d), _lib.ptr(gcol), g, s))
+        runs.append(gcol[:, :, :P].cpu().numpy())
+    assert cases.relerr(runs[0], exp) <= FWD_TOL
+    assert np.array_equal(runs[0], runs[1])
+    gw = torch.ones((G, Cog, Kg), device=DEV)     # accumulate semantics: starts at 1
+    _lib.check(L.ddcn_gemm_gweight_f32(_lib.ptr(gout_d), _lib.ptr(col_d), _lib.ptr(gw), g, s))
+    exp = 1.0 + np.einsum("ngop,ngkp->gok", gout.astype(np.float64), col.astype(np.float64))
+    assert cases.relerr(gw.cpu().numpy(), exp) <= BWD_TOL
