@@ -258,6 +258,23 @@ int ddcn_modulated_deform_conv_forward_f16(const void *x, const void *weight, co
                                            const void *mask, void *out, void *workspace, size_t workspace_bytes,
                                            const ddcn_geom *g, void *stream);
 
+/* The 16-bit forward WITHOUT a columns buffer ("an implicit-GEMM main op that never materialises columns";
+ * the reference's forward, PY:457-463 -> H:419-435, writes and re-reads 302 MB of columns per image at BASELINE config 5's
+ * layer4).  One kernel samples the B tile of every 32-k step (one tap x 32 channels) straight into LDS, from an input patch
+ * staged by DMA out of a channels-last copy of x, and multiplies it on v_mfma_f32_16x16x32 while the next step is being
+ * sampled.  Same arithmetic and the same rounding points as the columns path (a sample is rounded to 16 bits once, the
+ * sum accumulates in fp32).  Covered (ddcn_fused16_supported() == 0): 3x3 kernels, groups = 1, C and C/deformable_groups
+ * multiples of 32, Co a multiple of 8, a tile's input patch that fits LDS beside the weight ring (strides above 1 with a
+ * wide dilation do not).  workspace: ddcn_fused16_workspace_bytes() = the channels-last copy of x + the repacked weights. */
+int ddcn_fused16_supported(const ddcn_geom *g);
+size_t ddcn_fused16_workspace_bytes(const ddcn_geom *g);
+int ddcn_modulated_deform_conv_forward_fused_bf16(const void *x, const void *weight, const void *bias, const void *offset,
+                                                  const void *mask, void *out, void *workspace, size_t workspace_bytes,
+                                                  const ddcn_geom *g, void *stream);
+int ddcn_modulated_deform_conv_forward_fused_f16(const void *x, const void *weight, const void *bias, const void *offset,
+                                                 const void *mask, void *out, void *workspace, size_t workspace_bytes,
+                                                 const ddcn_geom *g, void *stream);
+
 /* G2 of the backward on 16-bit operands (the reference's half instantiation of H:305-308 / H:503-506): weight and grad_out
  * are bfloat16 / float16 tensors, the column gradients gcol[N][C*K2][ld] come out in fp32 (fp32 accumulation on
  * v_mfma_f32_16x16x32_{bf16,f16}), ready for ddcn_col2im_coord_f32.  `workspace` (ddcn_gemm_gcol_16_workspace_bytes)

@@ -608,6 +608,46 @@ int ddcn_modulated_deform_conv_forward_f16(const void *x, const void *weight, co
     return launch_forward_f16(x, weight, bias, offset, mask, out, workspace, *g, (hipStream_t)stream);
 }
 
+// ---------------------------------------------------------------- 16-bit forward without columns
+int ddcn_fused16_supported(const ddcn_geom *g)
+{
+    TRY(check_geom(g));
+    return fused16_supported(*g);
+}
+
+size_t ddcn_fused16_workspace_bytes(const ddcn_geom *g)
+{
+    if (check_geom(g) != DDCN_OK) return 0;
+    return fused16_workspace_bytes(*g);
+}
+
+static int fused_forward(bool bf16, const void *x, const void *weight, const void *bias, const void *offset, const void *mask,
+                         void *out, void *ws, size_t ws_bytes, const ddcn_geom *g, void *stream)
+{
+    REQUIRE(x); REQUIRE(weight); REQUIRE(offset); REQUIRE(out);
+    TRY(check_geom(g));
+    TRY(fused16_supported(*g));
+    if (!ws || ws_bytes < fused16_workspace_bytes(*g) || ((uintptr_t)ws & 15))
+        return fail(DDCN_ERR_WORKSPACE, "fused 16-bit forward: workspace of %zu bytes (16-byte aligned), need %zu", ws_bytes,
+                    fused16_workspace_bytes(*g));
+    return bf16 ? launch_fused_forward_bf16(x, weight, bias, offset, mask, out, ws, *g, (hipStream_t)stream)
+                : launch_fused_forward_f16(x, weight, bias, offset, mask, out, ws, *g, (hipStream_t)stream);
+}
+
+int ddcn_modulated_deform_conv_forward_fused_bf16(const void *x, const void *weight, const void *bias, const void *offset,
+                                                  const void *mask, void *out, void *workspace, size_t workspace_bytes,
+                                                  const ddcn_geom *g, void *stream)
+{
+    return fused_forward(true, x, weight, bias, offset, mask, out, workspace, workspace_bytes, g, stream);
+}
+
+int ddcn_modulated_deform_conv_forward_fused_f16(const void *x, const void *weight, const void *bias, const void *offset,
+                                                 const void *mask, void *out, void *workspace, size_t workspace_bytes,
+                                                 const ddcn_geom *g, void *stream)
+{
+    return fused_forward(false, x, weight, bias, offset, mask, out, workspace, workspace_bytes, g, stream);
+}
+
 // ---------------------------------------------------------------- 16-bit backward: G2 on 16-bit operands
 size_t ddcn_gemm_gcol_16_workspace_bytes(const ddcn_geom *g)
 {

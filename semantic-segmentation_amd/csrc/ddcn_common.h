@@ -107,6 +107,13 @@ int launch_gweight_bf16(const void *x, const void *offset, const void *mask, con
 int launch_gweight_f16(const void *x, const void *offset, const void *mask, const void *gout, float *gw, void *ws,
                        const ddcn_geom &g, hipStream_t stream);
 
+int fused16_supported(const ddcn_geom &g);
+size_t fused16_workspace_bytes(const ddcn_geom &g);
+int launch_fused_forward_bf16(const void *x, const void *weight, const void *bias, const void *offset, const void *mask,
+                              void *out, void *ws, const ddcn_geom &g, hipStream_t stream);
+int launch_fused_forward_f16(const void *x, const void *weight, const void *bias, const void *offset, const void *mask,
+                             void *out, void *ws, const ddcn_geom &g, hipStream_t stream);
+
 int launch_forward_f16(const void *x, const void *weight, const void *bias, const void *offset, const void *mask,
                        void *out, void *ws, const ddcn_geom &g, hipStream_t stream);
 

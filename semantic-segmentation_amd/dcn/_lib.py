@@ -78,6 +78,10 @@ PROTOTYPES = {
     "ddcn_workspace_bytes_bf16": [_G],
     "ddcn_bf16_supported": [_G],
     "ddcn_modulated_deform_conv_forward_bf16": [_P, _P, _P, _P, _P, _P, _P, _SZ, _G, _P],
+    "ddcn_fused16_supported": [_G],
+    "ddcn_fused16_workspace_bytes": [_G],
+    "ddcn_modulated_deform_conv_forward_fused_bf16": [_P, _P, _P, _P, _P, _P, _P, _SZ, _G, _P],
+    "ddcn_modulated_deform_conv_forward_fused_f16": [_P, _P, _P, _P, _P, _P, _P, _SZ, _G, _P],
     "ddcn_modulated_deform_conv_forward_f16": [_P, _P, _P, _P, _P, _P, _P, _SZ, _G, _P],
     "ddcn_gemm_gcol_16_workspace_bytes": [_G],
     "ddcn_gemm_gcol_16_supported": [_G],
@@ -99,6 +103,7 @@ _RESTYPES = {
     "ddcn_workspace_bytes": _SZ,
     "ddcn_static_scratch_bytes": _SZ,
     "ddcn_workspace_bytes_bf16": _SZ,
+    "ddcn_fused16_workspace_bytes": _SZ,
     "ddcn_gemm_gcol_16_workspace_bytes": _SZ,
     "ddcn_gweight_16_workspace_bytes": _SZ,
     "ddcn_workspace_bytes_f64": _SZ,

@@ -1,0 +1,105 @@
+"""GPU parity of the 16-bit forward WITHOUT a columns buffer (ddcn_modulated_deform_conv_forward_fused_{bf16,f16},
+SURVEY.md 8 f1: the implicit-GEMM main op; reference path PY:457-463 -> H:419-435 writes columns and multiplies them).
+
+Same two bars as the columns path (tests/test_gpu_bf16.py): end to end against the fp64 oracle on the same 16-bit inputs
+(1e-2 / 2e-3), and the tight bound against "16-bit columns, exact accumulation" (one output rounding + a quarter rounding of
+the tensor scale) -- the fused kernel rounds a sample to 16 bits exactly where the columns kernel does.  Plus: the columns
+path's own result is within two output roundings of the fused one (they differ in summation order only).
+"""
+import importlib
+
+import numpy as np
+import pytest
+import torch
+
+import cases
+import test_gpu_bf16 as tb
+from oracle import ddcn_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+if torch.cuda.is_available():
+    pkg = importlib.import_module("semantic-segmentation_amd")
+    _lib = importlib.import_module("semantic-segmentation_amd.dcn._lib")
+DEV = "cuda:0"
+
+FUSED_CASES = [
+    # every row-tile class of the kernel (Co 64 / 128 / 256 / 512 rows per workgroup), map edges inside tiles, dilations
+    dict(name="co64_dg2", N=1, C=64, Co=64, H=24, W=40, stride=1, pad=1, dil=1, groups=1, dg=2, mod=True, bias=True, sigma=2.0),
+    dict(name="co136_d2_n2", N=2, C=32, Co=136, H=19, W=23, stride=1, pad=2, dil=2, groups=1, dg=1, mod=True, bias=False, sigma=2.0),
+    dict(name="co200_d4_plain", N=1, C=64, Co=200, H=17, W=29, stride=1, pad=4, dil=4, groups=1, dg=2, mod=False, bias=True, sigma=2.0),
+    dict(name="co512_d4", N=1, C=96, Co=512, H=21, W=37, stride=1, pad=4, dil=4, groups=1, dg=3, mod=True, bias=True, sigma=2.0),
+    dict(name="co520_two_row_tiles", N=1, C=32, Co=520, H=9, W=17, stride=1, pad=1, dil=1, groups=1, dg=1, mod=True, bias=True, sigma=1.0),
+    dict(name="stride2", N=2, C=32, Co=64, H=21, W=18, stride=2, pad=1, dil=1, groups=1, dg=1, mod=True, bias=True, sigma=2.0),
+    dict(name="escapees_sigma12", N=1, C=64, Co=128, H=24, W=40, stride=1, pad=2, dil=2, groups=1, dg=2, mod=True, bias=False, sigma=12.0),
+    dict(name="zero_offsets", N=1, C=32, Co=64, H=16, W=16, stride=1, pad=1, dil=1, groups=1, dg=1, mod=True, bias=False, sigma=0.0),
+]
+
+
+def _inputs(c, seed=0):
+    rng = np.random.default_rng(seed)
+    Ho, Wo = orc.out_hw(c["H"], c["W"], 3, 3, c["stride"], c["pad"], c["dil"])
+    x = tb._bf(rng.standard_normal((c["N"], c["C"], c["H"], c["W"])))
+    w = tb._bf(rng.uniform(-1, 1, (c["Co"], c["C"], 3, 3)) / np.sqrt(c["C"] * 9))
+    off = tb._bf(c["sigma"] * rng.standard_normal((c["N"], c["dg"] * 18, Ho, Wo)))
+    mask = tb._bf(1 / (1 + np.exp(-rng.standard_normal((c["N"], c["dg"] * 9, Ho, Wo))))) if c["mod"] else None
+    bias = tb._bf(rng.standard_normal(c["Co"])) if c["bias"] else None
+    return x, off, mask, w, bias, Ho, Wo
+
+
+def _fused(c, dtype, tx, tw, tbias, toff, tmask, g):
+    L = _lib.lib()
+    assert L.ddcn_fused16_supported(g) == 0, _lib.lib().ddcn_last_error()
+    nbytes = L.ddcn_fused16_workspace_bytes(g)
+    assert nbytes >= (tx.numel() + tw.numel()) * 2
+    ws = torch.empty(nbytes // 2, dtype=dtype, device=DEV)
+    out = torch.full((c["N"], c["Co"], g.Ho, g.Wo), float("nan"), dtype=dtype, device=DEV)
+    entry = (L.ddcn_modulated_deform_conv_forward_fused_bf16 if dtype == torch.bfloat16
+             else L.ddcn_modulated_deform_conv_forward_fused_f16)
+    _lib.check(entry(_lib.ptr(tx), _lib.ptr(tw), _lib.ptr(tbias), _lib.ptr(toff), _lib.ptr(tmask), _lib.ptr(out),
+                     _lib.ptr(ws), nbytes, g, _lib.current_stream(tx.device)))
+    torch.cuda.synchronize()
+    return out
+
+
+@pytest.mark.parametrize("c", FUSED_CASES, ids=lambda c: c["name"])
+def test_fused_16bit_forward_matches_oracle_and_columns_path(c, fmt):
+    dtype, ulp, e2e_tol = fmt
+    x, off, mask, w, bias, Ho, Wo = _inputs(c)
+    g = _lib.Geom(c["N"], c["C"], c["H"], c["W"], c["Co"], 3, 3, c["stride"], c["stride"], c["pad"], c["pad"],
+                  c["dil"], c["dil"], 1, c["dg"], Ho, Wo)
+    tx, toff, tmask, tw, tbias = tb._t(x), tb._t(off), tb._t(mask), tb._t(w), tb._t(bias)
+    out = _fused(c, dtype, tx, tw, tbias, toff, tmask, g)
+    got = out.double().cpu().numpy()
+    assert np.isfinite(got).all()
+    exp = orc.deform_forward(x, off, mask, w, bias, c["stride"], c["pad"], c["dil"], 1, c["dg"])
+    assert cases.relerr(got, exp) <= e2e_tol, cases.relerr(got, exp)
+    tight = tb._exact_bf16_columns_result(dict(c, groups=1), x, off, mask, w, bias, Ho, Wo)
+    bound = ulp * np.abs(tight) + 4 * ulp * 0.0625 * np.abs(tight).max()
+    assert np.all(np.abs(got - tight) <= bound), float((np.abs(got - tight) / bound).max())
+    # the columns path on the same tensors: summation order is the only difference
+    if _lib.lib().ddcn_bf16_supported(g) == 0:
+        nb = _lib.lib().ddcn_workspace_bytes_bf16(g)
+        ws = torch.empty(nb // 2, dtype=dtype, device=DEV)
+        ref = torch.empty_like(out)
+        entry = (_lib.lib().ddcn_modulated_deform_conv_forward_bf16 if dtype == torch.bfloat16
+                 else _lib.lib().ddcn_modulated_deform_conv_forward_f16)
+        _lib.check(entry(_lib.ptr(tx), _lib.ptr(tw), _lib.ptr(tbias), _lib.ptr(toff), _lib.ptr(tmask), _lib.ptr(ref),
+                         _lib.ptr(ws), nb, g, _lib.current_stream(tx.device)))
+        d = (out.double() - ref.double()).abs().cpu().numpy()
+        assert np.all(d <= 2 * ulp * np.abs(tight) + 2 * ulp * 0.0625 * np.abs(tight).max())
+
+
+fmt = tb.fmt
+
+
+def test_fused_16bit_forward_rejects_what_it_does_not_cover():
+    L = _lib.lib()
+    bad = [
+        _lib.Geom(1, 48, 16, 16, 64, 3, 3, 1, 1, 1, 1, 1, 1, 1, 1, 16, 16),        # C not a multiple of 32
+        _lib.Geom(1, 64, 16, 16, 64, 3, 3, 1, 1, 1, 1, 1, 1, 2, 1, 16, 16),        # groups
+        _lib.Geom(1, 64, 16, 16, 64, 1, 1, 1, 1, 0, 0, 1, 1, 1, 1, 16, 16),        # 1x1
+        _lib.Geom(1, 64, 40, 40, 64, 3, 3, 2, 2, 6, 6, 6, 6, 1, 1, 20, 20),        # stride 2 with dilation 6: patch too large
+    ]
+    for g in bad:
+        assert L.ddcn_fused16_supported(g) == -5 and L.ddcn_fused16_workspace_bytes(g) == 0

@@ -41,20 +41,38 @@ def main():
         def run():
             _lib.check(L.ddcn_modulated_deform_conv_forward_bf16(p(x), p(w), None, p(off), p(mask), p(out), p(ws),
                                                                  nbytes, g, s))
-        for _ in range(3):
-            run()
-        torch.cuda.synchronize()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(iters):
-            run()
-        e1.record()
-        torch.cuda.synchronize()
-        ms = e0.elapsed_time(e1) / iters
+
+        def timed(fn):
+            for _ in range(3):
+                fn()
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(iters):
+                fn()
+            e1.record()
+            torch.cuda.synchronize()
+            return e0.elapsed_time(e1) / iters
+        ms = timed(run)
         flops = 2.0 * C * C * 9 * P
         gbytes = 2.0 * (C * H * W + 27 * dg * P + C * 9 * P)
         print("%-26s %.3f ms   GEMM %.1f GFLOP (%.0f TFLOP/s if alone)   im2col %.0f MB (%.0f GB/s if alone)"
               % (name, ms, flops / 1e9, flops / ms / 1e9, gbytes / 1e6, gbytes / ms / 1e6))
+        # the same layer without a columns buffer (ddcn_fused16.hip)
+        if L.ddcn_fused16_supported(g) == 0:
+            fbytes = L.ddcn_fused16_workspace_bytes(g)
+            fws = torch.empty(fbytes // 2, dtype=torch.bfloat16, device=dev)
+            out2 = torch.empty_like(out)
+
+            def run_fused():
+                _lib.check(L.ddcn_modulated_deform_conv_forward_fused_bf16(p(x), p(w), None, p(off), p(mask), p(out2),
+                                                                           p(fws), fbytes, g, s))
+            msf = timed(run_fused)
+            run()
+            torch.cuda.synchronize()
+            diff = float((out.float() - out2.float()).abs().max() / out.float().abs().max())
+            print("%-26s %.3f ms   fused, no columns: %.0f TFLOP/s for the whole call; max |fused - columns| / max = %.1e"
+                  % ("", msf, flops / msf / 1e9, diff))
 
 
 if __name__ == "__main__":
