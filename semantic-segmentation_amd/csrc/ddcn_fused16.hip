@@ -4,9 +4,10 @@
 // element for element what ddcn_bf16.hip computes through its columns buffer (same blend, same rounding of a sample).
 //
 // One workgroup (512 threads, 8 waves as 4 row groups x 2 column groups) owns a tile of 8 x 16 output pixels and up to
-// 512 output channels.  The contraction runs in steps of 32 k = ONE tap x 32 input channels:
+// 256 output channels (more: several workgroups per pixel tile, each sampling for itself).  The contraction runs in
+// steps of 32 k = ONE tap x 32 input channels:
 //   A  the weights of the step, repacked per call to [step][Co][32] (64 bytes per row), go global -> LDS by DMA through a
-//      ring of two stages (row chunks XOR-swizzled for conflict-free 16x16x32 fragment reads, as in gemm16_dma_kernel);
+//      ring of four stages (row chunks XOR-swizzled for conflict-free 16x16x32 fragment reads, as in gemm16_dma_kernel);
 //   B  is SAMPLED: every thread owns one (pixel, channel octet) of the step, reads the four corners of the tap's sample
 //      position from the input patch in LDS (one ds_read_b128 per corner = eight channels), blends them in fp32, rounds
 //      once and writes the 16-byte octet -- exactly one MFMA B fragment -- into the step's B tile (4 octets x 128 pixels).
@@ -14,8 +15,13 @@
 //      channels-last copy of the input (made per call: a cell's 32 channels are 64 contiguous bytes there), double
 //      buffered across channel blocks, its cells outside the image zero-filled by the DMA's range check; samples whose
 //      corners leave the patch gather their corners from the channels-last copy directly.
-//   While the MFMAs of step s run, the same waves sample step s + 1 and the DMA brings A(s + 1) and an eighth of the next
-//   channel block's patch: one barrier per step.
+//   A step samples B(s + 1), requests a piece of the next channel block's patch and A(s + 3) (the ring has four stages, so a
+//   request has two whole steps to land: the wait at the end of a step allows the two newest steps' requests to be in
+//   flight), runs the MFMAs of step s and ends in ONE barrier.
+//
+// Measured (profiles/r03c_fused16.txt): equal to the columns path at C = 128, slower at C = 256 and 512 -- the sampling
+// arithmetic that im2col hides under its HBM writes here competes with the MFMAs for issue slots.  The entry points are
+// therefore opt-in; the default 16-bit forward stays im2col + GEMM.
 #include "ddcn_16bit.h"
 
 #include <stdlib.h>
@@ -29,6 +35,7 @@ constexpr int FT = 512;                     // threads
 constexpr int FTH = 8, FTW = 16, FPIX = 128;   // output pixels of a tile
 constexpr int FCB = 32;                     // input channels per block = k of one step
 constexpr int FLDS_MAX = 160 * 1024;
+constexpr int FNST = 4;                     // stages of the weight ring
 constexpr int FMAXPIECE = 8;                // patch DMA requests per thread and block (one per tap 0..7)
 
 struct FusedArgs {
@@ -94,10 +101,10 @@ __global__ __launch_bounds__(FT, 1) void fused16_kernel(const FusedArgs a)
 {
     constexpr int BMF = 4 * RT * 16;                    // rows of the workgroup tile
     constexpr int RA = (BMF * 4 + FT - 1) / FT;         // A requests per thread and step (BMF * 4 chunks of 16 bytes)
-    constexpr int RING = BMF * 4, BT = 4 * FPIX;        // 16-byte units per ring stage / per B tile
+    constexpr int RING = RA * FT, BT = 4 * FPIX;        // 16-byte units per ring stage (whole requests) / per B tile
     extern __shared__ u32x4 lds[];
-    u32x4 *ring = lds;                                  // [2][BMF][4]
-    u32x4 *btile = lds + 2 * RING;                      // [2][4][128]
+    u32x4 *ring = lds;                                  // [FNST][RING]
+    u32x4 *btile = lds + FNST * RING;                   // [2][4][128]
     u32x4 *patch = btile + 2 * BT;                      // [2][npiece * 512 slots]: RS cells x 4 octets, padded to whole DMA pieces
     const int PSTR = a.npiece * FT;                     // (a piece's lanes beyond RS * 4 write zeros: they must stay inside the buffer)
 
@@ -126,16 +133,18 @@ __global__ __launch_bounds__(FT, 1) void fused16_kernel(const FusedArgs a)
     for (int r = 0; r < RA; ++r) {
         const int q = (r * 8 + wave) * 64 + lane;
         const int row = q >> 2, c = (q & 3) ^ a_swizzle(row);
-        offA[r] = (q < BMF * 4 && m0 + row < a.Co) ? (unsigned)(((m0 + row) * 32 + c * 8) * 2) : DMA_OOB;
+        offA[r] = (row < BMF && m0 + row < a.Co) ? (unsigned)(((m0 + row) * 32 + c * 8) * 2) : DMA_OOB;
     }
+    const int nsteps = a.nblocks * 9;
+    // every wave issues exactly RA requests per step, also past the last step (out of range: zeros into a free stage), so
+    // that the vmcnt arithmetic of sync_step holds to the end
     auto request_a = [&](int step) {
-        char *base = (char *)(ring + (step & 1) * RING) + wave * 1024;
+        char *base = (char *)(ring + (step & (FNST - 1)) * RING) + wave * 1024;
+        const bool real = step < nsteps;
 #pragma unroll
         for (int r = 0; r < RA; ++r) {
-            if ((r * 8 + wave) * 64 < BMF * 4) {          // uniform: requests beyond the stage are not issued at all
-                const unsigned va = offA[r] != DMA_OOB ? offA[r] + (unsigned)(step * a.Co * 64) : DMA_OOB;
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, (lds_void *)(base + r * 8192), 16, va, 0, 0, 0);
-            }
+            const unsigned va = (real && offA[r] != DMA_OOB) ? offA[r] + (unsigned)(step * a.Co * 64) : DMA_OOB;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, (lds_void *)(base + r * 8192), 16, va, 0, 0, 0);
         }
     };
     // patch requests: piece j of wave w fills patch slots (j * 8 + w) * 64 + lane; slot -> (cell, position) -> channel octet
@@ -220,7 +229,7 @@ __global__ __launch_bounds__(FT, 1) void fused16_kernel(const FusedArgs a)
 #pragma unroll
             for (int e = 0; e < 4; ++e) acc[i][j][e] = 0.f;
     auto mfmas = [&](int step) {
-        const u32x4 *As = ring + (step & 1) * RING, *Bs = btile + (step & 1) * BT;
+        const u32x4 *As = ring + (step & (FNST - 1)) * RING, *Bs = btile + (step & 1) * BT;
         u32x4 fb[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) fb[j] = Bs[kc * FPIX + wn * 64 + j * 16 + r16];
@@ -232,43 +241,51 @@ __global__ __launch_bounds__(FT, 1) void fused16_kernel(const FusedArgs a)
             for (int j = 0; j < 4; ++j) acc[i][j] = T::mfma16(fa, fb[j], acc[i][j]);
         }
     };
+    // the end of a step: this wave's LDS writes are done and its requests have landed, except the A requests of the two
+    // newest steps (requests complete in order, and a step's patch piece is issued before its A requests, so a piece is
+    // complete one step after its own)
     auto sync_step = [&]() {
-        __builtin_amdgcn_s_waitcnt(wait_vm_lgkm0(0));     // this wave's DMA pieces have landed, its LDS writes are done
+        __builtin_amdgcn_s_waitcnt(wait_vm_lgkm0(2 * RA));
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+    };
+    auto sync_all = [&]() {
+        __builtin_amdgcn_s_waitcnt(wait_vm_lgkm0(0));
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
     };
 
-    // prologue: the whole patch of block 0, A of step 0, the first group's offsets; then step 0 is sampled
+    // prologue: the whole patch of block 0, the first group's offsets, A of steps 0..2; then step 0 is sampled
 #pragma unroll
     for (int j = 0; j < FMAXPIECE; ++j) request_patch(0, j);
-    request_a(0);
     load_offsets(0);
-    sync_step();
+    sync_all();
     sample(0, 0, 0);
     if (a.nblocks > 1) request_patch(1, 0);
-    sync_step();
+    request_a(0);
+    request_a(1);
+    request_a(2);
+    sync_step();                                        // A(0) has landed
 
-    const int nsteps = a.nblocks * 9;
     for (int cb = 0; cb < a.nblocks; ++cb) {
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
             const int step = cb * 9 + tap;
-            // prepare step + 1 (A by DMA, B by sampling, a piece of the next block's patch) beside the MFMAs of this step
             if (tap < 8) {
-                request_a(step + 1);
-                if (cb + 1 < a.nblocks && tap + 1 < 8) request_patch(cb + 1, tap + 1);
                 sample(cb, tap + 1, step + 1);
+                if (cb + 1 < a.nblocks && tap + 1 < 8) request_patch(cb + 1, tap + 1);
             } else if (step + 1 < nsteps) {
-                request_a(step + 1);
                 const int g0 = (cb * FCB) / a.cpg, g1 = ((cb + 1) * FCB) / a.cpg;
                 if (g1 != g0) load_offsets(g1);
-                if (cb + 2 < a.nblocks) request_patch(cb + 2, 0);
                 sample(cb + 1, 0, step + 1);
+                if (cb + 2 < a.nblocks) request_patch(cb + 2, 0);
             }
+            request_a(step + 3);
             mfmas(step);
             sync_step();
         }
     }
+    __builtin_amdgcn_s_waitcnt(wait_vm_lgkm0(0));       // the out-of-range requests of the last steps, before the LDS is given back
 
     // lane l holds rows 4 * (l / 16) + e, column l % 16 of each 16 x 16 tile; column tile j of wave column wn = tile row wn * 4 + j
     const bf16_t *bias = a.bias;
@@ -298,8 +315,8 @@ bool fused_plan(const ddcn_geom &g, FusedPlan &pl, const char **why)
     if (g.groups != 1) { *why = "groups must be 1"; return false; }
     if (g.C % FCB || (g.C / g.dg) % FCB) { *why = "C and C/deformable_groups must be multiples of 32"; return false; }
     if (g.Co % 8) { *why = "Co must be a multiple of 8"; return false; }
-    pl.RT = g.Co > 256 ? 8 : (g.Co > 128 ? 4 : (g.Co > 64 ? 2 : 1));
-    const size_t fixed = (size_t)2 * (4 * pl.RT * 16) * 64 + (size_t)2 * 4 * FPIX * 16;
+    pl.RT = g.Co > 128 ? 4 : (g.Co > 64 ? 2 : 1);       // more than 256 output channels: several workgroups per pixel tile
+    const size_t fixed = (size_t)FNST * std::max(4 * pl.RT * 16 * 4, FT) * 16 + (size_t)2 * 4 * FPIX * 16;
     int M = 6;
     for (; M >= 1; --M) {
         pl.RH = (FTH - 1) * g.sh + 2 * g.dh + 2 * M + 2;
@@ -375,8 +392,7 @@ static int fused_forward_16(const void *x, const void *weight, const void *bias,
         if (mask) DDCN_F16_LAUNCH(true, RTV);                                                                        \
         else DDCN_F16_LAUNCH(false, RTV);                                                                            \
     } while (0)
-    if (pl.RT == 8) DDCN_F16_LAUNCH_RT(8);
-    else if (pl.RT == 4) DDCN_F16_LAUNCH_RT(4);
+    if (pl.RT == 4) DDCN_F16_LAUNCH_RT(4);
     else if (pl.RT == 2) DDCN_F16_LAUNCH_RT(2);
     else DDCN_F16_LAUNCH_RT(1);
 #undef DDCN_F16_LAUNCH_RT

@@ -2,7 +2,7 @@
 
 Per layer: the whole call (im2col_bf16 + gemm_bf16) with HIP events; rocprofv3 --kernel-trace --stats of this
 script gives the split.  Algorithmic bytes im2col = 2*(C*H*W + 27*dg*P + C*9*P); flops = 2*Co*C*9*P.
-usage: python tools/bench_bf16.py [iters]
+usage: python tools/bench_bf16.py [iters]     (DDCN_BENCH_SIGMA = standard deviation of the offsets in pixels, default 2)
 """
 import importlib
 import os
@@ -24,6 +24,7 @@ LAYERS = [  # layer1 at 1/4 resolution, the dilated stage
 def main():
     iters = int(sys.argv[1]) if len(sys.argv) > 1 else 20
     dev, dg = "cuda:0", 4
+    sigma = float(os.environ.get("DDCN_BENCH_SIGMA", 2))
     L, p = _lib.lib(), _lib.ptr
     for name, C, H, W, d in LAYERS:
         g = _lib.Geom(1, C, H, W, C, 3, 3, 1, 1, d, d, d, d, 1, dg, H, W)
@@ -31,7 +32,7 @@ def main():
         P = H * W
         x = torch.randn(1, C, H, W, device=dev).bfloat16()
         w = (torch.randn(C, C, 3, 3, device=dev) / (C * 9) ** 0.5).bfloat16()
-        off = (2 * torch.randn(1, dg * 18, H, W, device=dev)).bfloat16()
+        off = (sigma * torch.randn(1, dg * 18, H, W, device=dev)).bfloat16()
         mask = torch.sigmoid(torch.randn(1, dg * 9, H, W, device=dev)).bfloat16()
         out = torch.empty(1, C, H, W, device=dev, dtype=torch.bfloat16)
         nbytes = L.ddcn_workspace_bytes_bf16(g)
