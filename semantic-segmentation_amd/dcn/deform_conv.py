@@ -92,6 +92,9 @@ SAVE_COLUMNS = os.environ.get("DDCN_SAVE_COLUMNS", "1") != "0"
 # columns, MFMA with fp32 accumulation (BASELINE config 5).  DDCN_BF16_NATIVE=0, a geometry they do not cover, or any tensor that
 # requires grad selects the fp32 kernels (convert in, compute, convert out).
 BF16_NATIVE = os.environ.get("DDCN_BF16_NATIVE", "1") != "0"
+# DDCN_BF16_FUSED=1: the 16-bit forward without a columns buffer (ddcn_modulated_deform_conv_forward_fused_{bf16,f16})
+# where it covers the geometry.  Opt-in: equal to im2col + GEMM at C = 128, slower beyond (profiles/r03c_fused16.txt).
+BF16_FUSED = os.environ.get("DDCN_BF16_FUSED", "0") == "1"
 
 
 # Saved-columns fp32 backward on two streams (ddcn_deform_conv_backward_saved_2s_f32): the weight-gradient GEMM runs on
@@ -226,10 +229,15 @@ def _bf16_forward(input, offset, mask, weight, bias, g):
     L = _lib.lib()
     if not BF16_NATIVE or L.ddcn_bf16_supported(g) != 0:
         return None
-    entry = (L.ddcn_modulated_deform_conv_forward_bf16 if input.dtype == torch.bfloat16
-             else L.ddcn_modulated_deform_conv_forward_f16)
     output = input.new_empty((g.N, g.Co, g.Ho, g.Wo))
-    nbytes = L.ddcn_workspace_bytes_bf16(g)
+    if BF16_FUSED and L.ddcn_fused16_supported(g) == 0:
+        entry = (L.ddcn_modulated_deform_conv_forward_fused_bf16 if input.dtype == torch.bfloat16
+                 else L.ddcn_modulated_deform_conv_forward_fused_f16)
+        nbytes = L.ddcn_fused16_workspace_bytes(g)
+    else:
+        entry = (L.ddcn_modulated_deform_conv_forward_bf16 if input.dtype == torch.bfloat16
+                 else L.ddcn_modulated_deform_conv_forward_f16)
+        nbytes = L.ddcn_workspace_bytes_bf16(g)
     ws = torch.empty(nbytes // 2, dtype=input.dtype, device=input.device)
     with torch.cuda.device(input.device):
         _lib.check(entry(

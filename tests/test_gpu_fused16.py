@@ -32,6 +32,9 @@ FUSED_CASES = [
     dict(name="co520_two_row_tiles", N=1, C=32, Co=520, H=9, W=17, stride=1, pad=1, dil=1, groups=1, dg=1, mod=True, bias=True, sigma=1.0),
     dict(name="stride2", N=2, C=32, Co=64, H=21, W=18, stride=2, pad=1, dil=1, groups=1, dg=1, mod=True, bias=True, sigma=2.0),
     dict(name="escapees_sigma12", N=1, C=64, Co=128, H=24, W=40, stride=1, pad=2, dil=2, groups=1, dg=2, mod=True, bias=False, sigma=12.0),
+    # four channel blocks on one deformable group, wide offsets: both patch buffers in use, samples in the patch's first and
+    # last cells (the DMA padding of a patch buffer once spilled zeros into the first cells of the other one)
+    dict(name="c128_four_blocks", N=1, C=128, Co=64, H=40, W=48, stride=1, pad=1, dil=1, groups=1, dg=1, mod=True, bias=True, sigma=3.0),
     dict(name="zero_offsets", N=1, C=32, Co=64, H=16, W=16, stride=1, pad=1, dil=1, groups=1, dg=1, mod=True, bias=False, sigma=0.0),
 ]
 
