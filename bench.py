@@ -82,6 +82,10 @@ def make_inputs(w, dev, seed):
     return [t.to(dev) for t in (x, weight, offset, mask, gout)]
 
 
+LDS_ATOMIC64_CYCLES, N_CU, CLOCK_HZ = 22, 256, 2.4e9   # measured wave-instruction cost; MI355X_MICROARCH.md
+PREHEAT_STEPS = 20      # untimed steps before the warm-up of the layer workload (see main)
+
+
 def time_stage(fn, iters, warmup=2):
     for _ in range(warmup):
         fn()
@@ -134,6 +138,17 @@ def kernel_rooflines(w, tensors, iters):
             ach, peak, unit = work / ms / 1e9, MFMA_F32_PEAK_TF, "TFLOP/s"
         res.append(dict(kernel=name, bound=bound, ms=round(ms, 4), achieved=round(ach, 2), peak=peak, unit=unit,
                         frac=round(ach / peak, 4), traffic=traffic.get(name), work=work))
+        if name == "col2im_coord":
+            # the scatter's real bound is the LDS-atomic rate, not HBM: four atomics per (pixel, tap,
+            # channel) into the workgroup's LDS footprint, two channels per ds_add_u64 in the default packed fixed-point
+            # format (DDCN_SCATTER_FX=0: one ds_add_u64 per channel); a CU retires one 64-bit wave atomic per ~22 cycles
+            # whatever the addresses (tools/ubench_lds_atomic.hip)
+            packed = os.environ.get("DDCN_SCATTER_FX", "1") != "0"
+            winstr = N * w["C"] * w["H"] * w["W"] * 9 * 4 / 64 / (2 if packed else 1)
+            floor_ms = winstr * LDS_ATOMIC64_CYCLES / (N_CU * CLOCK_HZ) * 1e3
+            res[-1]["lds_atomic"] = {"wave_instructions": int(winstr), "cycles_per_instruction_per_cu": LDS_ATOMIC64_CYCLES,
+                                     "floor_ms": round(floor_ms, 4), "frac": round(floor_ms / ms, 4),
+                                     "format": "2 channels per ds_add_u64" if packed else "1 channel per ds_add_u64"}
     return res, traffic_src
 
 
@@ -476,6 +491,9 @@ def main():
                          "PyTorch's / rocBLAS's bf16 kernels of the DANet head (DESIGN.md section 6); not for shared machines")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--no-other-schedule", action="store_true",
+                    help="layer: do not also time the step under the other backward schedule (for a rocprofv3 run whose "
+                         "per-kernel averages should describe the default schedule only)")
     args = ap.parse_args()
     if args.gpus < 1:
         raise SystemExit("--gpus must be >= 1")
@@ -541,6 +559,10 @@ def main():
         if world > 1:   # data-parallel gradient exchange of the layer's parameter (SUM then /world)
             dist_utils.allreduce_grads([weight])
 
+    # set-up, before the W warm-up steps: the first ~50 ms of GPU work in a fresh process run 2 % slow (clock ramp, the
+    # caching allocator's first blocks), which would otherwise be charged to whichever schedule is timed first
+    for _ in range(PREHEAT_STEPS):
+        step()
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
@@ -564,7 +586,7 @@ def main():
     dcn = importlib.import_module("semantic-segmentation_amd.dcn.deform_conv")
     default_two = bool(dcn.TWO_STREAM_BACKWARD)
     alt = None
-    if world == 1:
+    if world == 1 and not args.no_other_schedule:
         dcn.TWO_STREAM_BACKWARD = not default_two
         for _ in range(max(1, args.warmup)):
             step()
@@ -590,7 +612,7 @@ def main():
         "config": {"workload": "BASELINE configs[0] layer: modulated DDCN 3x3, N=%d/GPU, C=%d->%d, %dx%d, "
                                "stride 1, pad=dil=%d, groups 1, dg 1, fwd+bwd" %
                                (w["N"], w["C"], w["Co"], w["H"], w["W"], w["dil"]),
-                   "images_per_gpu": w["N"], "parallelism": "dp%d" % world,
+                   "images_per_gpu": w["N"], "parallelism": "dp%d" % world, "preheat_steps": PREHEAT_STEPS,
                    "alg_bytes_per_image": a["b_total"], "alg_flops_per_image": a["f_total"],
                    "backward_schedule": "two streams (G3 beside the scatter)" if default_two else
                                         "one stream: every kernel runs alone, in order"},
