@@ -82,7 +82,7 @@ def make_inputs(w, dev, seed):
     return [t.to(dev) for t in (x, weight, offset, mask, gout)]
 
 
-LDS_ATOMIC64_CYCLES, N_CU, CLOCK_HZ = 22, 256, 2.4e9   # measured wave-instruction cost; MI355X_MICROARCH.md
+LDS_ATOMIC64_CYCLES, N_CU, CLOCK_HZ = 19, 256, 2.4e9   # measured wave-instruction cost; MI355X_MICROARCH.md
 PREHEAT_STEPS = 20      # untimed steps before the warm-up of the layer workload (see main)
 
 
@@ -141,7 +141,7 @@ def kernel_rooflines(w, tensors, iters):
         if name == "col2im_coord":
             # the scatter's real bound is the LDS-atomic rate, not HBM: four atomics per (pixel, tap,
             # channel) into the workgroup's LDS footprint, two channels per ds_add_u64 in the default packed fixed-point
-            # format (DDCN_SCATTER_FX=0: one ds_add_u64 per channel); a CU retires one 64-bit wave atomic per ~22 cycles
+            # format (DDCN_SCATTER_FX=0: one ds_add_u64 per channel); a CU retires one ds_add_u64 wave instruction per ~19 cycles
             # whatever the addresses (tools/ubench_lds_atomic.hip)
             packed = os.environ.get("DDCN_SCATTER_FX", "1") != "0"
             winstr = N * w["C"] * w["H"] * w["W"] * 9 * 4 / 64 / (2 if packed else 1)
