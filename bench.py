@@ -561,7 +561,8 @@ def main():
 
     # set-up, before the W warm-up steps: the first ~50 ms of GPU work in a fresh process run 2 % slow (clock ramp, the
     # caching allocator's first blocks), which would otherwise be charged to whichever schedule is timed first
-    for _ in range(PREHEAT_STEPS):
+    preheat = 0 if (world > 1 and args.backend == "gloo") else PREHEAT_STEPS   # the one-GPU gloo rehearsal stays short
+    for _ in range(preheat):
         step()
     for _ in range(args.warmup):
         step()
@@ -612,7 +613,7 @@ def main():
         "config": {"workload": "BASELINE configs[0] layer: modulated DDCN 3x3, N=%d/GPU, C=%d->%d, %dx%d, "
                                "stride 1, pad=dil=%d, groups 1, dg 1, fwd+bwd" %
                                (w["N"], w["C"], w["Co"], w["H"], w["W"], w["dil"]),
-                   "images_per_gpu": w["N"], "parallelism": "dp%d" % world, "preheat_steps": PREHEAT_STEPS,
+                   "images_per_gpu": w["N"], "parallelism": "dp%d" % world, "preheat_steps": preheat,
                    "alg_bytes_per_image": a["b_total"], "alg_flops_per_image": a["f_total"],
                    "backward_schedule": "two streams (G3 beside the scatter)" if default_two else
                                         "one stream: every kernel runs alone, in order"},

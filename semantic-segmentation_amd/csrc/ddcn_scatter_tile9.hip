@@ -3,7 +3,7 @@
 // Arithmetic: detseg/ops/dcn/src/deform_conv_cuda_kernel.cu K:278-334 / K:634-692 (col2im) and K:372-435 /
 // K:694-766 (col2im_coord), helpers K:116-187.  Formula-by-formula citations are in ddcn_gather.hip.
 //
-// workgroup = (TH x TW tile of output pixels, group of input channels, image n); thread = output pixel.
+// workgroup = (TH x TW tile of output pixels, group of CG input channels, image n); thread = output pixel.
 //   registers : per tap the patch cell, the fractional parts and the mask of the pixel's sample, and four
 //               running sums S_i = sum_c gcol[c,k,p] * x[c, corner_i].  grad_offset and grad_mask are linear
 //               in the S_i (K:163-184, K:752), so they are formed once at the end, not per channel.
@@ -42,10 +42,7 @@ struct Tile9Args {
     int P, cpg;
     long ld;
     int TH, TW, tiles_w, tiles, groups;
-    // channel groups: every deformable group is cut into gpd groups of ubase (the first urem of them: ubase + 1) units of
-    // SCU channels -- uneven on purpose, so that the number of workgroups can be fitted to whole rounds of the chip
-    int gpd, ubase, urem, SCU;
-    int M;
+    int CG, M;
     int RH, RW, RS;
     int esc_cells;       // adaptive kernel: cost of one escaped sample in patch cells
     int Mw_max;          // adaptive kernel: largest margin the wide (2-channel) footprint can take; 0 = never wide
@@ -56,15 +53,6 @@ struct Tile9Args {
 };
 
 constexpr int SKB_MAX = 12;
-
-// first channel and channel count of channel group grp
-__device__ __forceinline__ void group_range(const Tile9Args &a, int grp, int &cg0, int &cgn)
-{
-    const int dgi = grp / a.gpd, gi = grp - dgi * a.gpd;
-    const int u0 = gi * a.ubase + min(gi, a.urem);
-    cg0 = dgi * a.cpg + u0 * a.SCU;
-    cgn = (a.ubase + (gi < a.urem ? 1 : 0)) * a.SCU;
-}
 
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t s9_rsrc(const void *base, long bytes)
 {
@@ -136,8 +124,7 @@ __device__ __forceinline__ void tile9_body(const Tile9Args &a, const PatchGeom p
     const int rh0 = tyi * a.TH * g.sh - g.ph - pg.M;
     const int rw0 = txi * a.TW * g.sw - g.pw - pg.M;
     const int n = blockIdx.z;
-    int cg0, cgn;
-    group_range(a, grp, cg0, cgn);
+    const int cg0 = grp * a.CG;
     const int dgi = cg0 / a.cpg;
     const int HW = g.H * g.W;
     const int p = live ? ho * g.Wo + wo : 0;
@@ -303,7 +290,7 @@ __device__ __forceinline__ void tile9_body(const Tile9Args &a, const PatchGeom p
     wstage_store();
 
     const unsigned pvo = (live && !SKB) ? (unsigned)(p * 4) : SOOB;   // direct mode: every column load is rejected
-    const int nchunks = cgn / SC;
+    const int nchunks = a.CG / SC;
     // column values of the current chunk; each tap reloads its registers for the next chunk as soon as it is done
     float gcv[K2][SC];
 #pragma unroll
@@ -525,11 +512,11 @@ __device__ __forceinline__ void tile9_body(const Tile9Args &a, const PatchGeom p
             const float *im = a.x + ((long)n * g.C + cg0) * HW;
             float *gim = gxn + (long)cg0 * HW;
             const float *gcp = a.gcol + (((long)n * g.C + cg0) * K2 + k) * a.ld + p;
-            for (int c0 = 0; c0 < cgn; c0 += 4) {
+            for (int c0 = 0; c0 < a.CG; c0 += 4) {
                 float gc[4], r1[4], r2[4], r3[4], r4[4];
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
-                    const int c = min(c0 + u, cgn - 1);
+                    const int c = min(c0 + u, a.CG - 1);
                     if (SKB) {
                         const float *wr = a.sk_w + ((long)(cg0 + c) * K2 + k) * SKB;
                         float v = 0.f;
@@ -544,7 +531,7 @@ __device__ __forceinline__ void tile9_body(const Tile9Args &a, const PatchGeom p
                 }
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
-                    if (c0 + u < cgn) {
+                    if (c0 + u < a.CG) {
                         const float v1 = ok1 ? r1[u] : 0.f, v2 = ok2 ? r2[u] : 0.f;
                         const float v3 = ok3 ? r3[u] : 0.f, v4 = ok4 ? r4[u] : 0.f;
                         S1[k] += gc[u] * v1; S2[k] += gc[u] * v2; S3[k] += gc[u] * v3; S4[k] += gc[u] * v4;
@@ -617,7 +604,7 @@ __global__ __launch_bounds__(ST, SCN == 4 ? 2 : DDCN_S9_WPS) void col2im_coord_t
     const int ho = tyi * a.TH + ty, wo = txi * a.TW + tx;
     const bool live = ty < a.TH && ho < g.Ho && wo < g.Wo;
     const int n = blockIdx.z;
-    const int dgi = grp / a.gpd;
+    const int dgi = grp * a.CG / a.cpg;
     const int p = live ? ho * g.Wo + wo : 0;
     // margin-0 patch of the tile: rows rh0 .. rh0 + RH0 - 1
     const int rh0 = tyi * a.TH * g.sh - g.ph, rw0 = txi * a.TW * g.sw - g.pw;
@@ -754,42 +741,11 @@ int launch_col2im_coord_tile9(const float *gcol, const float *x, const float *of
         }
     }
     if (!ok) return DDCN_OK;
-    // Channel groups per deformable group.  A workgroup costs its chunks plus a prologue worth ~1.6 four-channel chunks
-    // (offsets, classification, headroom histogram, first staging: fitted on config 1, 32 vs 128 channels per group), and
-    // the launch runs in rounds of `slots` workgroups: cost(gpd) = ceil(W0 * gpd / slots) * (ceil(U / gpd) + P0).  The
-    // groups may be uneven (group_range), so gpd need not divide the channel count: config 1 takes 6 groups of 84 / 88
-    // channels = 480 workgroups = ONE round instead of 16 groups = 2.5 rounds.
-    static const int env_model = getenv("DDCN_SCATTER_SPLIT_MODEL") ? atoi(getenv("DDCN_SCATTER_SPLIT_MODEL")) : 1;
-    static const int env_gpd = getenv("DDCN_SCATTER_GPD") ? atoi(getenv("DDCN_SCATTER_GPD")) : 0;
-    const int U = d.cpg / SC;
-    int gpd;
-    if (env_model) {
-        static thread_local int cached_dev = -1, cached_cus = 256;
-        int dev = 0;
-        if (hipGetDevice(&dev) == hipSuccess && dev != cached_dev) {
-            int n = 0;
-            cached_cus = (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) ? n : 256;
-            cached_dev = dev;
-        }
-        const int cus = cached_cus;
-        const long slots = (long)cus * (SC == 4 ? 2 : DDCN_S9_WPS);
-        const long W0 = (long)a.tiles * g.N * g.dg;
-        const double P0 = 1.6 * 4 / SC;
-        double best = 0.0;
-        gpd = 1;
-        for (int c = 1; c <= U; ++c) {
-            const double cost = (double)((W0 * c + slots - 1) / slots) * ((U + c - 1) / c + P0);
-            if (c == 1 || cost < best) { best = cost; gpd = c; }
-        }
-    } else {
-        int CG = d.cpg;
-        while (CG % (2 * SC) == 0 && (long)a.tiles * g.N * (g.C / CG) < 1024) CG /= 2;
-        gpd = d.cpg / CG;
-    }
-    if (env_cg > 0 && d.cpg % env_cg == 0 && env_cg % SC == 0) gpd = d.cpg / env_cg;
-    if (env_gpd > 0 && env_gpd <= U) gpd = env_gpd;
-    a.gpd = gpd; a.SCU = SC; a.ubase = U / gpd; a.urem = U % gpd;
-    a.groups = g.dg * gpd;
+    int CG = d.cpg;
+    while (CG % (2 * SC) == 0 && (long)a.tiles * g.N * (g.C / CG) < 1024) CG /= 2;
+    if (env_cg > 0 && d.cpg % env_cg == 0 && env_cg % SC == 0) CG = env_cg;
+    a.CG = CG;
+    a.groups = g.C / CG;
     *handled = true;
     a.gcol = gcol; a.x = x; a.offset = offset; a.mask = mask; a.gx = gx; a.goff = goff; a.gmask = gmask;
     a.g = g; a.P = d.P; a.cpg = d.cpg; a.ld = d.ld;

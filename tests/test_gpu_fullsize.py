@@ -169,31 +169,6 @@ def test_full_size_16bit_training_step_native_against_fp32_kernels(dtype, monkey
         assert cases.relerr(u.double().cpu().numpy(), v.double().cpu().numpy()) <= tol, name
 
 
-def test_full_size_bf16_training_step_one_image_against_fp64_oracle():
-    """One image of the bench layer (C=512->512, 97x97, pad=dil=4) on bf16 tensors, native 16-bit forward and backward
-    (16-bit columns, G2 and G3 on 16-bit operands over the pixel-octet grid, fp32 scatter), against the fp64 oracle on the
-    same bf16-representable inputs.  bf16 offsets are exact in the kernels' fp32 coordinate arithmetic, so no sample
-    changes cell; the bar is the format's end-to-end tolerance of tests/test_gpu_bf16.py (1e-2 of each tensor's scale)."""
-    import test_gpu_bf16 as tb
-    c = dict(name="bench_layer_image", N=1, C=512, Co=512, H=97, W=97, stride=1, pad=4, dil=4, groups=1, dg=1, mod=True,
-             bias=False)
-    x, off, mask, w, _, Ho, Wo = tb._inputs(c, seed=41)
-    gout = tb._bf(np.random.default_rng(42).standard_normal((1, 512, Ho, Wo)))
-    g = _lib.Geom(1, 512, 97, 97, 512, 3, 3, 1, 1, 4, 4, 4, 4, 1, 1, Ho, Wo)
-    assert _lib.lib().ddcn_gemm_gcol_16_supported(g) == 0 and _lib.lib().ddcn_gweight_16_supported(g) == 0
-    t = [tb._t(a).requires_grad_(True) for a in (x, off, mask, w)]
-    out = pkg.modulated_deform_conv(t[0], t[1], t[2], t[3], None, 1, 4, 4, 1, 1)
-    out.backward(tb._t(gout))
-    torch.cuda.synchronize()
-    eout = orc.deform_forward(x, off, mask, w, None, 1, 4, 4, 1, 1)
-    egx, egoff, egmask, egw, _ = orc.deform_backward(x, off, mask, w, gout, False, 1, 4, 4, 1, 1)
-    for name, got, exp in (("out", out.detach(), eout), ("gx", t[0].grad, egx), ("goff", t[1].grad, egoff),
-                           ("gmask", t[2].grad, egmask), ("gw", t[3].grad, egw)):
-        assert got.dtype == torch.bfloat16, name
-        err = cases.relerr(got.double().cpu().numpy(), exp)
-        assert err <= 1e-2, (name, err)
-
-
 # ---------------------------------------------------------------- 16-bit training at the R101 layer shapes, batch 8
 def test_16bit_training_r101_layer_shapes_batch8_after_a_smaller_call(monkeypatch):
     """The three DDCN layer shapes of BASELINE configs[2] (DDCN-R101, 769x769, batch 8: layer2's stride-2 layer 193x193 ->
