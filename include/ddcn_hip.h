@@ -265,7 +265,9 @@ int ddcn_modulated_deform_conv_forward_f16(const void *x, const void *weight, co
  * sampled.  Same arithmetic and the same rounding points as the columns path (a sample is rounded to 16 bits once, the
  * sum accumulates in fp32).  Covered (ddcn_fused16_supported() == 0): 3x3 kernels, groups = 1, C and C/deformable_groups
  * multiples of 32, Co a multiple of 8, a tile's input patch that fits LDS beside the weight ring (strides above 1 with a
- * wide dilation do not).  workspace: ddcn_fused16_workspace_bytes() = the channels-last copy of x + the repacked weights. */
+ * wide dilation do not).  workspace: ddcn_fused16_workspace_bytes() = the channels-last copy of x + the repacked weights.
+ * Opt-in (the Python layer takes it with DDCN_BF16_FUSED=1): measured equal to the columns path at C = 128 and slower at
+ * C >= 256 (profiles/r03c_fused16.txt) -- for callers that cannot afford the columns workspace, not for speed. */
 int ddcn_fused16_supported(const ddcn_geom *g);
 size_t ddcn_fused16_workspace_bytes(const ddcn_geom *g);
 int ddcn_modulated_deform_conv_forward_fused_bf16(const void *x, const void *weight, const void *bias, const void *offset,
@@ -280,7 +282,7 @@ int ddcn_modulated_deform_conv_forward_fused_f16(const void *x, const void *weig
  * v_mfma_f32_16x16x32_{bf16,f16}), ready for ddcn_col2im_coord_f32.  `workspace` (ddcn_gemm_gcol_16_workspace_bytes)
  * takes the repacked operands.  Covered: Co/groups a multiple of 8 (ddcn_gemm_gcol_16_supported() == 0); any kernel
  * size.  Used by the autograd functions for half / bfloat16 training: forward on the native 16-bit kernels, G2 here,
- * scatter / im2col / G3 on the fp32 kernels (a 16-bit G3 needs the columns in pixel octets: DESIGN.md section 8). */
+ * G3 through ddcn_deform_conv_gweight_{bf16,f16} below, the scatter on the fp32 kernel. */
 size_t ddcn_gemm_gcol_16_workspace_bytes(const ddcn_geom *g);
 int ddcn_gemm_gcol_16_supported(const ddcn_geom *g);
 int ddcn_gemm_gcol_bf16(const void *weight, const void *grad_out, float *gcol, void *workspace, size_t workspace_bytes,
