@@ -139,17 +139,21 @@ def kernel_rooflines(w, tensors, iters):
         res.append(dict(kernel=name, bound=bound, ms=round(ms, 4), achieved=round(ach, 2), peak=peak, unit=unit,
                         frac=round(ach / peak, 4), traffic=traffic.get(name), work=work))
         if name == "col2im_coord":
-            # the scatter's real bound is the LDS-atomic rate, not HBM: four atomics per (pixel, tap,
-            # channel) into the workgroup's LDS footprint, two channels per ds_add_u64 in the default packed fixed-point
-            # format (DDCN_SCATTER_FX=0: one ds_add_u64 per channel); a CU retires one ds_add_u64 wave instruction per ~19 cycles
-            # whatever the addresses (tools/ubench_lds_atomic.hip)
-            packed = os.environ.get("DDCN_SCATTER_FX", "1") != "0"
-            winstr = N * w["C"] * w["H"] * w["W"] * 9 * 4 / 64 / (2 if packed else 1)
-            floor_ms = winstr * LDS_ATOMIC64_CYCLES / (N_CU * CLOCK_HZ) * 1e3
-            res[-1]["lds_atomic"] = {"wave_instructions": int(winstr), "cycles_per_instruction_per_cu": LDS_ATOMIC64_CYCLES,
-                                     "floor_ms": round(floor_ms, 4), "frac": round(floor_ms / ms, 4),
-                                     "format": "2 channels per ds_add_u64" if packed else "1 channel per ds_add_u64"}
+            res[-1]["lds_atomic"] = lds_atomic_floor(w, ms)
     return res, traffic_src
+
+
+def lds_atomic_floor(w, ms):
+    """The scatter's real bound is the LDS-atomic rate, not HBM: four atomics per (pixel, tap, channel) into
+    the workgroup's LDS footprint, two channels per ds_add_u64 in the default packed fixed-point format
+    (DDCN_SCATTER_FX=0: one ds_add_u64 per channel); a CU retires one ds_add_u64 wave instruction per ~19 cycles whatever
+    the addresses (tools/ubench_lds_atomic.hip).  -> the floor in ms and the measured launch as a fraction of it."""
+    packed = os.environ.get("DDCN_SCATTER_FX", "1") != "0"
+    winstr = w["N"] * w["C"] * w["H"] * w["W"] * 9 * 4 / 64 / (2 if packed else 1)
+    floor_ms = winstr * LDS_ATOMIC64_CYCLES / (N_CU * CLOCK_HZ) * 1e3
+    return {"wave_instructions": int(winstr), "cycles_per_instruction_per_cu": LDS_ATOMIC64_CYCLES,
+            "floor_ms": round(floor_ms, 4), "frac": round(floor_ms / ms, 4),
+            "format": "2 channels per ds_add_u64" if packed else "1 channel per ds_add_u64"}
 
 
 def csrc_digest():
